@@ -1,0 +1,157 @@
+"""ctypes binding of libreactranker_hip.so (the C-ABI in include/reactranker_hip.h).
+
+This is the only place the shared library is loaded.  There is no fallback: if the
+library is missing or a call returns a non-zero status, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libreactranker_hip.so")
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+c_stream = C.c_void_p
+i64 = C.c_int64
+i32 = C.c_int
+u64 = C.c_uint64
+f32 = C.c_float
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [
+        ("M", i64), ("N", i32),
+        ("a1", c_f32p), ("lda1", i64), ("k1", i32), ("a1_idx", c_i32p),
+        ("a1_sub", c_f32p), ("lda1_sub", i64), ("a1_sub_idx", c_i32p),
+        ("a2", c_f32p), ("lda2", i64), ("k2", i32),
+        ("a_mask", c_f32p), ("ld_mask", i64), ("mask_scale", f32),
+        ("w", c_f32p), ("ldw", i64),
+        ("bias", c_f32p),
+        ("residual", c_f32p), ("ldr", i64),
+        ("act", i32), ("drop_p", f32), ("drop_seed", u64),
+        ("c", c_f32p), ("ldc", i64),
+        ("c_pre", c_f32p), ("ld_pre", i64),
+    ]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("M", i64), ("N", i32),
+        ("dy", c_f32p), ("ld_dy", i64),
+        ("mask", c_f32p), ("ld_mask", i64), ("mask_scale", f32),
+        ("x1", c_f32p), ("ldx1", i64), ("k1", i32), ("x1_idx", c_i32p),
+        ("x1_sub", c_f32p), ("ldx1_sub", i64), ("x1_sub_idx", c_i32p),
+        ("x2", c_f32p), ("ldx2", i64), ("k2", i32),
+        ("dw", c_f32p), ("ld_dw", i64),
+        ("dbias", c_f32p),
+        ("accumulate", i32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+_SIGS = {
+    "rr_strerror": (C.c_char_p, [i32]),
+    "rr_version": (i32, []),
+    "rr_abi_struct_sizes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "rr_gather_sum_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, c_stream]),
+    "rr_gather_diff_f32": (i32, [c_f32p, i64, i64, c_i32p, c_f32p, i64, i64, c_i32p, i64, i32, c_f32p, i64, c_stream]),
+    "rr_colsum_workspace_bytes": (C.c_size_t, [i64, i32]),
+    "rr_weighted_colsum_f32": (i32, [c_f32p, i64, i64, c_f32p, i32, c_f32p, i32, C.c_void_p, C.c_size_t, c_stream]),
+    "rr_linear_f32": (i32, [C.POINTER(LinearArgs), c_stream]),
+    "rr_linear_wgrad_workspace_bytes": (C.c_size_t, [i64, i32, i32]),
+    "rr_linear_wgrad_f32": (i32, [C.POINTER(WgradArgs), c_stream]),
+    "rr_dropout_keep_host": (i32, [u64, u64, f32]),
+    "rr_dropout_f32": (i32, [c_f32p, i64, f32, u64, c_f32p, c_stream]),
+    "rr_relu_bwd_f32": (i32, [c_f32p, c_f32p, f32, c_f32p, c_f32p, i64, c_stream]),
+    "rr_axpby_f32": (i32, [f32, c_f32p, f32, c_f32p, c_f32p, i64, c_stream]),
+    "rr_head_fwd_f32": (i32, [c_f32p, i64, i32, i32, c_f32p, c_stream]),
+    "rr_head_bwd_f32": (i32, [c_f32p, c_f32p, i64, i32, i32, c_f32p, c_stream]),
+    "rr_segment_mean_fwd_f32": (i32, [c_f32p, i64, c_i32p, i64, i32, c_f32p, i32, f32, u64, c_f32p, i64, c_stream]),
+    "rr_segment_mean_bwd_f32": (i32, [c_f32p, i64, c_i32p, c_i32p, i64, i32, i32, f32, u64, c_f32p, i64, c_stream]),
+    "rr_listmle_fwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, c_stream]),
+    "rr_listmle_bwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, i64, c_stream]),
+    "rr_listnet_fwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, i64, c_f32p, c_f32p, c_stream]),
+    "rr_listnet_bwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, i64, c_f32p, c_f32p, i64, c_stream]),
+    "rr_evidential_ranking_fwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, c_stream]),
+    "rr_evidential_ranking_bwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, c_f32p,
+                                            i64, c_stream]),
+    "rr_ranknet_fwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, f32, c_f32p, C.c_void_p, c_f32p, c_stream]),
+    "rr_ranknet_bwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, f32, i32, c_f32p, c_f32p, i64, c_stream]),
+    "rr_pointwise_partial_count": (i64, [i64]),
+    "rr_mse_fwd_f32": (i32, [c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, c_stream]),
+    "rr_mse_bwd_f32": (i32, [c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, i64, c_stream]),
+    "rr_gauss_nll_fwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, c_stream]),
+    "rr_gauss_nll_bwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
+    "rr_logcumsumexp_fwd_f32": (i32, [c_f32p, i32, c_f32p, c_stream]),
+    "rr_logcumsumexp_bwd_f32": (i32, [c_f32p, c_f32p, c_f32p, i32, c_f32p, c_stream]),
+    "rr_pack_sizes": (i32, [C.c_void_p, C.c_void_p, i64, C.c_void_p, i32, C.POINTER(i64), C.POINTER(i64),
+                            C.POINTER(C.c_int32)]),
+    "rr_pack_graphs": (i32, [C.c_void_p, C.c_void_p, i64, C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, i32, C.c_void_p, i64, C.c_void_p, i64, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p]),
+    "rr_derive_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, C.c_void_p, i64, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
+ABI_VERSION = 1
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises loudly (no fallback) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"reactranker_amd: native library not found at {LIB_PATH}. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C reactranker_amd/csrc`. "
+                "There is no CPU/eager fallback for the product path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)           # AttributeError here = ABI mismatch, also loud
+            fn.restype = res
+            fn.argtypes = args
+        if l.rr_version() != ABI_VERSION:
+            raise RuntimeError(f"reactranker_amd: ABI version mismatch ({l.rr_version()} != {ABI_VERSION}); rebuild")
+        sl, sw = C.c_size_t(), C.c_size_t()
+        l.rr_abi_struct_sizes(C.byref(sl), C.byref(sw))
+        if sl.value != C.sizeof(LinearArgs) or sw.value != C.sizeof(WgradArgs):
+            raise RuntimeError("reactranker_amd: ctypes struct layout differs from the compiled header")
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().rr_strerror(status).decode()
+        raise RuntimeError(f"reactranker_hip {what} failed: {msg} (status {status})")
+
+
+def ptr(t):
+    """Device/host pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def np_ptr(a):
+    if a is None:
+        return None
+    return C.c_void_p(a.ctypes.data)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"reactranker_amd: `{name}` must live on the GPU (got {t.device}); "
+                           "the HIP path has no CPU fallback")

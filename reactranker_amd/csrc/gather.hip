@@ -1,0 +1,252 @@
+// Gather / segment kernels of the D-MPNN message-passing path (HBM-bound, no MFMA).
+//
+// Rows are H contiguous floats (H = 300 -> 75 float4).  Threads are laid out flat over
+// (row, float4-column) so a wave always issues full 16-byte lanes and consecutive lanes
+// read consecutive addresses of one source row; a molecule's rows sit next to each other
+// in memory, so the K neighbour rows of a destination are L2-resident and each source row
+// leaves HBM once (algorithmic bytes: DESIGN.md section 4).
+#include "rr_common.h"
+
+namespace {
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> { using T = f32x4; };
+template <> struct Vec<1> { using T = float; };
+
+template <int VEC>
+__device__ inline typename Vec<VEC>::T ld(const float* p) {
+  return *reinterpret_cast<const typename Vec<VEC>::T*>(p);
+}
+template <int VEC>
+__device__ inline void st(float* p, typename Vec<VEC>::T v) {
+  *reinterpret_cast<typename Vec<VEC>::T*>(p) = v;
+}
+
+// out[r] = sum_k src[idx[r,k]]   (idx < 0 skipped)
+template <int VEC>
+__global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                         const int32_t* __restrict__ idx, int64_t n_out, int K,
+                                                         int HV, float* __restrict__ out, int64_t ld_out) {
+  using V = typename Vec<VEC>::T;
+  const int64_t total = n_out * HV;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / HV;
+    const int c = static_cast<int>(e - r * HV) * VEC;
+    const int32_t* ir = idx + r * K;
+    V acc = V(0.0f);
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {          // 4 independent row loads in flight
+      const int32_t j0 = ir[k], j1 = ir[k + 1], j2 = ir[k + 2], j3 = ir[k + 3];
+      V v0 = V(0.0f), v1 = V(0.0f), v2 = V(0.0f), v3 = V(0.0f);
+      if (j0 >= 0) v0 = ld<VEC>(src + j0 * ld_src + c);
+      if (j1 >= 0) v1 = ld<VEC>(src + j1 * ld_src + c);
+      if (j2 >= 0) v2 = ld<VEC>(src + j2 * ld_src + c);
+      if (j3 >= 0) v3 = ld<VEC>(src + j3 * ld_src + c);
+      acc = (((acc + v0) + v1) + v2) + v3;   // k order, like sum(dim=1)
+    }
+    for (; k < K; ++k) {
+      const int32_t j = ir[k];
+      if (j >= 0) acc = acc + ld<VEC>(src + j * ld_src + c);
+    }
+    st<VEC>(out + r * ld_out + c, acc);
+  }
+}
+
+// out[r] = a[ia[r]] - m[im[r]]
+template <int VEC>
+__global__ void __launch_bounds__(256) gather_diff_kernel(const float* __restrict__ a, int64_t ld_a,
+                                                          const int32_t* __restrict__ ia,
+                                                          const float* __restrict__ m, int64_t ld_m,
+                                                          const int32_t* __restrict__ im, int64_t n_out, int HV,
+                                                          float* __restrict__ out, int64_t ld_out) {
+  using V = typename Vec<VEC>::T;
+  const int64_t total = n_out * HV;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / HV;
+    const int c = static_cast<int>(e - r * HV) * VEC;
+    const int32_t ja = ia[r], jm = im[r];
+    V va = V(0.0f), vm = V(0.0f);
+    if (ja >= 0) va = ld<VEC>(a + ja * ld_a + c);
+    if (jm >= 0) vm = ld<VEC>(m + jm * ld_m + c);
+    st<VEC>(out + r * ld_out + c, va - vm);
+  }
+}
+
+// stage 1 of the deterministic weighted column sum: block b sums its row chunk.
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, int64_t n, int64_t ld,
+                                                             const float* __restrict__ w, int H,
+                                                             int64_t rows_per_block, float* __restrict__ partial) {
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      const float w0 = w ? w[r] : 1.f, w1 = w ? w[r + 1] : 1.f, w2 = w ? w[r + 2] : 1.f, w3 = w ? w[r + 3] : 1.f;
+      a0 += w0 * x[r * ld + c];
+      a1 += w1 * x[(r + 1) * ld + c];
+      a2 += w2 * x[(r + 2) * ld + c];
+      a3 += w3 * x[(r + 3) * ld + c];
+    }
+    for (; r < r1; ++r) a0 += (w ? w[r] : 1.f) * x[r * ld + c];
+    partial[static_cast<int64_t>(blockIdx.x) * H + c] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+// stage 2: fixed-order sum over the block partials.
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int nblocks, int H,
+                                                           float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float acc = 0.f;
+  for (int b = 0; b < nblocks; ++b) acc += partial[static_cast<int64_t>(b) * H + c];
+  out[c] = accumulate ? out[c] + acc : acc;
+}
+
+// out[m, 0:H] = mean of x rows [start, start+size); out[m, H:H+F] = feat[m]; optional dropout.
+__global__ void __launch_bounds__(256) segment_mean_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const int32_t* __restrict__ a_scope, int64_t M, int H,
+                                                               const float* __restrict__ feat, int F, uint32_t thr,
+                                                               float keep_scale, uint64_t seed,
+                                                               float* __restrict__ out, int64_t ld_out) {
+  const int W = H + F;
+  const int64_t total = M * W;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t m = e / W;
+    const int c = static_cast<int>(e - m * W);
+    float v;
+    if (c < H) {
+      const int32_t start = a_scope[2 * m], size = a_scope[2 * m + 1];
+      float acc = 0.f;
+      for (int32_t i = 0; i < size; ++i) acc += x[(static_cast<int64_t>(start) + i) * ldx + c];
+      v = size > 0 ? acc / static_cast<float>(size) : 0.f;
+    } else {
+      v = feat[m * F + (c - H)];
+    }
+    if (thr != 0u) v = rr_keep(seed, static_cast<uint64_t>(e), thr) ? v * keep_scale : 0.f;
+    out[m * ld_out + c] = v;
+  }
+}
+
+// dx[a] = dout[mol(a)] * keep/(1-p) / size(mol(a))
+__global__ void __launch_bounds__(256) segment_mean_bwd_kernel(const float* __restrict__ dout, int64_t ld_dout,
+                                                               const int32_t* __restrict__ a_scope,
+                                                               const int32_t* __restrict__ atom2mol, int64_t n_atoms,
+                                                               int H, int F, uint32_t thr, float keep_scale,
+                                                               uint64_t seed, float* __restrict__ dx, int64_t ldx) {
+  const int64_t total = n_atoms * H;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int W = H + F;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t a = e / H;
+    const int c = static_cast<int>(e - a * H);
+    const int32_t m = atom2mol[a];
+    float v = 0.f;
+    if (m >= 0) {
+      const int32_t size = a_scope[2 * static_cast<int64_t>(m) + 1];
+      v = dout[static_cast<int64_t>(m) * ld_dout + c] / static_cast<float>(size);
+      if (thr != 0u)
+        v = rr_keep(seed, static_cast<uint64_t>(m) * W + c, thr) ? v * keep_scale : 0.f;
+    }
+    dx[a * ldx + c] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rr_gather_sum_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
+                      int H, float* out, int64_t ld_out, rr_stream_t stream) {
+  RR_CHECK_ARG(src && idx && out && n_src >= 0 && n_out >= 0 && K >= 1 && H >= 1 && ld_src >= H && ld_out >= H);
+  if (n_out == 0) return RR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(out);
+  if (vec) {
+    const int HV = H / 4;
+    gather_sum_kernel<4><<<rr_grid_for(n_out * HV, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out);
+  } else {
+    gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out);
+  }
+  return rr_launch_status();
+}
+
+int rr_gather_diff_f32(const float* a, int64_t n_a, int64_t ld_a, const int32_t* ia, const float* m, int64_t n_m,
+                       int64_t ld_m, const int32_t* im, int64_t n_out, int H, float* out, int64_t ld_out,
+                       rr_stream_t stream) {
+  RR_CHECK_ARG(a && ia && m && im && out && n_a >= 0 && n_m >= 0 && n_out >= 0 && H >= 1 && ld_a >= H &&
+               ld_m >= H && ld_out >= H);
+  if (n_out == 0) return RR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (H % 4 == 0) && (ld_a % 4 == 0) && (ld_m % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(a) &&
+                   rr_aligned16(m) && rr_aligned16(out);
+  if (vec) {
+    const int HV = H / 4;
+    gather_diff_kernel<4><<<rr_grid_for(n_out * HV, 256), 256, 0, s>>>(a, ld_a, ia, m, ld_m, im, n_out, HV, out,
+                                                                       ld_out);
+  } else {
+    gather_diff_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(a, ld_a, ia, m, ld_m, im, n_out, H, out,
+                                                                      ld_out);
+  }
+  return rr_launch_status();
+}
+
+static int colsum_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;   // >= 256 rows per block
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return static_cast<int>(b);
+}
+
+size_t rr_colsum_workspace_bytes(int64_t n, int H) {
+  if (n < 0 || H < 1) return 0;
+  return static_cast<size_t>(colsum_blocks(n)) * static_cast<size_t>(H) * sizeof(float);
+}
+
+int rr_weighted_colsum_f32(const float* x, int64_t n, int64_t ld, const float* w, int H, float* out, int accumulate,
+                           void* workspace, size_t workspace_bytes, rr_stream_t stream) {
+  RR_CHECK_ARG(x && out && workspace && n >= 0 && H >= 1 && ld >= H);
+  if (workspace_bytes < rr_colsum_workspace_bytes(n, H)) return RR_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nb = colsum_blocks(n);
+  const int64_t rpb = (n + nb - 1) / nb;
+  float* partial = static_cast<float*>(workspace);
+  colsum_partial_kernel<<<nb, 256, 0, s>>>(x, n, ld, w, H, rpb > 0 ? rpb : 1, partial);
+  colsum_final_kernel<<<(H + 255) / 256, 256, 0, s>>>(partial, nb, H, out, accumulate);
+  return rr_launch_status();
+}
+
+int rr_segment_mean_fwd_f32(const float* x, int64_t ldx, const int32_t* a_scope, int64_t M, int H, const float* feat,
+                            int F, float drop_p, uint64_t drop_seed, float* out, int64_t ld_out,
+                            rr_stream_t stream) {
+  RR_CHECK_ARG(x && a_scope && out && M >= 0 && H >= 1 && F >= 0 && ldx >= H && ld_out >= H + F);
+  RR_CHECK_ARG(F == 0 || feat);
+  RR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  if (M == 0) return RR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint32_t thr = rr_drop_threshold(drop_p);
+  segment_mean_fwd_kernel<<<rr_grid_for(M * (H + F), 256), 256, 0, s>>>(x, ldx, a_scope, M, H, feat, F, thr,
+                                                                         1.0f / (1.0f - drop_p), drop_seed, out,
+                                                                         ld_out);
+  return rr_launch_status();
+}
+
+int rr_segment_mean_bwd_f32(const float* dout, int64_t ld_dout, const int32_t* a_scope, const int32_t* atom2mol,
+                            int64_t n_atoms, int H, int F, float drop_p, uint64_t drop_seed, float* dx, int64_t ldx,
+                            rr_stream_t stream) {
+  RR_CHECK_ARG(dout && a_scope && atom2mol && dx && n_atoms >= 0 && H >= 1 && F >= 0 && ld_dout >= H && ldx >= H);
+  RR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  if (n_atoms == 0) return RR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint32_t thr = rr_drop_threshold(drop_p);
+  segment_mean_bwd_kernel<<<rr_grid_for(n_atoms * H, 256), 256, 0, s>>>(dout, ld_dout, a_scope, atom2mol, n_atoms, H,
+                                                                        F, thr, 1.0f / (1.0f - drop_p), drop_seed, dx,
+                                                                        ldx);
+  return rr_launch_status();
+}
+
+}  // extern "C"

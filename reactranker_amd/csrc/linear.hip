@@ -1,0 +1,554 @@
+// Dense layers of the D-MPNN path on the exact-f32 matrix core (v_mfma_f32_16x16x4_f32).
+//
+//   rr_linear_f32        C = dropout(act(residual + bias + [A1|A2] * W^T))   (forward, and dX with W^T)
+//   rr_linear_wgrad_f32  dW = dZ^T * [X1|X2],  dbias = colsum(dZ)            (weight gradients)
+//
+// Both fuse the reference's surrounding ATen ops into the operand load / epilogue:
+// row gather + subtract (a_message[b2a] - message[b2revb], models/mpn.py:91-92), the
+// concat of two sources (models/mpn.py:103, 208, 217), ReLU/dropout backward masks, bias,
+// residual add, ReLU and dropout (models/mpn.py:94-97).
+//
+// Geometry (forward): workgroup = 4 waves = 64 rows of A x up to 304 output columns
+// (19 MFMA tiles of 16), so the streamed / gathered operand A leaves HBM exactly once and
+// the small weight matrix is served from L2.  K is walked in 16-wide tiles, double
+// buffered in LDS (47 KB -> 3 workgroups per CU), one barrier per tile.  The MFMA is fed
+// with W as its "A" operand and the activations as "B", so a lane's 4 accumulator
+// registers are 4 consecutive output columns of one row: the epilogue is 16-byte loads and
+// stores.  LDS rows are 64 B with the four 16-byte chunks XOR-swizzled so that
+// ds_read_b128 fragment reads are bank-conflict free.
+//
+// f32 MFMA is bit-for-bit an fmaf chain (no reduced precision anywhere); results differ
+// from the CPU reference only by summation order.
+#include "rr_common.h"
+
+namespace {
+
+constexpr int BM = 64;      // rows per workgroup
+constexpr int BK = 16;      // k-tile
+constexpr int THREADS = 256;
+
+enum : int {
+  F_A1_VEC = 1, F_A2_VEC = 2, F_SUB_VEC = 4, F_MASK_VEC = 8, F_W1_VEC = 16, F_W2_VEC = 32, F_EPI_VEC = 64, F_PRE_VEC = 128
+};
+
+struct LinearParams {
+  rr_linear_args a;
+  int t1, t2;           // k-tiles of segment 1 / 2
+  int flags;
+  uint32_t drop_thr;
+  float keep_scale;
+};
+
+__device__ __forceinline__ int swz(int row, int kq) { return kq ^ ((0 - (row >> 2)) & 3); }
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// 4 consecutive floats p[k..k+3] of a row with `ks` valid columns; columns >= ks read as 0.
+__device__ __forceinline__ f32x4 load_chunk(const float* p, int k, int ks, bool vec) {
+  f32x4 v = f32x4(0.f);
+  if (p == nullptr || k >= ks) return v;
+  if (vec) {
+    v = ld4(p + k);
+    if (k + 3 >= ks) {
+      if (k + 1 >= ks) v.y = 0.f;
+      if (k + 2 >= ks) v.z = 0.f;
+      v.w = 0.f;
+    }
+  } else {
+    v.x = p[k];
+    if (k + 1 < ks) v.y = p[k + 1];
+    if (k + 2 < ks) v.z = p[k + 2];
+    if (k + 3 < ks) v.w = p[k + 3];
+  }
+  return v;
+}
+
+__device__ __forceinline__ f32x4 apply_mask(f32x4 v, f32x4 mk, float scale) {
+  v.x = mk.x > 0.f ? v.x * scale : 0.f;
+  v.y = mk.y > 0.f ? v.y * scale : 0.f;
+  v.z = mk.z > 0.f ? v.z * scale : 0.f;
+  v.w = mk.w > 0.f ? v.w * scale : 0.f;
+  return v;
+}
+
+// MODE: 0 plain / concat, 1 = A1 minus a second (optionally gathered) source, 2 = ReLU-backward mask on A
+template <int NT, int MODE>
+__global__ void __launch_bounds__(THREADS) linear_kernel(const LinearParams P) {
+  constexpr int BN = 16 * NT;
+  constexpr int B_ITERS = (BN * 4 + THREADS - 1) / THREADS;     // float4 chunks of the W tile per thread
+  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BK];
+
+  const rr_linear_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
+  const int n0 = blockIdx.y * BN;
+  const int flags = P.flags;
+
+  // ---- this thread's staging assignment: one 16-byte chunk of A, B_ITERS chunks of W per k-tile
+  const int srow = tid >> 2, skq = tid & 3;
+  const int64_t sm = m0 + srow;
+  const float* rowp1 = nullptr;
+  const float* rowp2 = nullptr;
+  const float* subp = nullptr;
+  const float* maskp = nullptr;
+  if (sm < a.M) {
+    if (a.k1 > 0) {
+      if (a.a1_idx) {
+        const int32_t j = a.a1_idx[sm];
+        if (j >= 0) rowp1 = a.a1 + static_cast<int64_t>(j) * a.lda1;
+      } else {
+        rowp1 = a.a1 + sm * a.lda1;
+      }
+      if (MODE == 1 && a.a1_sub) {
+        if (a.a1_sub_idx) {
+          const int32_t j = a.a1_sub_idx[sm];
+          if (j >= 0) subp = a.a1_sub + static_cast<int64_t>(j) * a.lda1_sub;
+        } else {
+          subp = a.a1_sub + sm * a.lda1_sub;
+        }
+      }
+    }
+    if (a.k2 > 0) rowp2 = a.a2 + sm * a.lda2;
+    if (MODE == 2) maskp = a.a_mask + sm * a.ld_mask;
+  }
+  const int ktot = a.k1 + a.k2;
+  (void)ktot;
+
+  auto load_a = [&](int kt) -> f32x4 {
+    f32x4 v;
+    if (kt < P.t1) {
+      const int k = kt * BK + skq * 4;
+      v = load_chunk(rowp1, k, a.k1, flags & F_A1_VEC);
+      if (MODE == 1) v = v - load_chunk(subp, k, a.k1, flags & F_SUB_VEC);
+      if (MODE == 2) v = apply_mask(v, load_chunk(maskp, k, a.k1, flags & F_MASK_VEC), a.mask_scale);
+    } else {
+      const int k = (kt - P.t1) * BK + skq * 4;
+      v = load_chunk(rowp2, k, a.k2, flags & F_A2_VEC);
+    }
+    return v;
+  };
+  auto load_w = [&](int kt, int it) -> f32x4 {
+    const int f = it * THREADS + tid;            // chunk id inside the W tile
+    const int wr = f >> 2;                       // tile row (output column), kq == skq
+    const int n = n0 + wr;
+    if (wr >= BN || n >= a.N) return f32x4(0.f);
+    const float* wp = a.w + static_cast<int64_t>(n) * a.ldw;
+    if (kt < P.t1) return load_chunk(wp, kt * BK + skq * 4, a.k1, flags & F_W1_VEC);
+    return load_chunk(wp + a.k1, (kt - P.t1) * BK + skq * 4, a.k2, flags & F_W2_VEC);
+  };
+  auto store_tile = [&](int buf, const f32x4& ra, const f32x4 (&rb)[B_ITERS]) {
+    float* As = lds[buf];
+    float* Bs = lds[buf] + BM * BK;
+    *reinterpret_cast<f32x4*>(As + srow * BK + 4 * swz(srow, skq)) = ra;
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      const int wr = (it * THREADS + tid) >> 2;
+      if (wr < BN) *reinterpret_cast<f32x4*>(Bs + wr * BK + 4 * swz(wr, skq)) = rb[it];
+    }
+  };
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4(0.f);
+
+  const int nk = P.t1 + P.t2;
+  f32x4 ra;
+  f32x4 rb[B_ITERS];
+  ra = load_a(0);
+#pragma unroll
+  for (int it = 0; it < B_ITERS; ++it) rb[it] = load_w(0, it);
+  store_tile(0, ra, rb);
+  __syncthreads();
+
+  const int fr = lane & 15, fkq = lane >> 4;
+  const int a_off = (wave * 16 + fr) * BK + 4 * swz(fr, fkq);
+  const int b_off = fr * BK + 4 * swz(fr, fkq);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {                                   // next tile's global loads fly during the MFMAs
+      ra = load_a(kt + 1);
+#pragma unroll
+      for (int it = 0; it < B_ITERS; ++it) rb[it] = load_w(kt + 1, it);
+    }
+    const float* As = lds[cur];
+    const float* Bs = lds[cur] + BM * BK;
+    const f32x4 af = ld4(As + a_off);
+    constexpr int G = 5;                          // column tiles per group: MFMA dependency distance >= 4
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += G) {
+      f32x4 wf[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (t0 + g < NT) wf[g] = ld4(Bs + (t0 + g) * 16 * BK + b_off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (t0 + g < NT) acc[t0 + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][j], af[j], acc[t0 + g], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(cur ^ 1, ra, rb);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m][n .. n+3] per tile: m = row (lane&15), n = tile*16 + (lane>>4)*4
+  const int64_t m = m0 + wave * 16 + fr;
+  if (m >= a.M) return;
+  const int nq = fkq * 4;
+  float* crow = a.c + m * a.ldc;
+  const float* rrow = a.residual ? a.residual + m * a.ldr : nullptr;
+  const bool evec = flags & F_EPI_VEC;
+#pragma unroll
+  for (int tc = 0; tc < NT; ++tc) {
+    const int n = n0 + tc * 16 + nq;
+    if (n >= a.N) continue;
+    f32x4 v = acc[tc];
+    if (evec) {
+      if (a.bias) v = v + ld4(a.bias + n);
+      if (rrow) v = v + ld4(rrow + n);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e < a.N) {
+          if (a.bias) v[e] += a.bias[n + e];
+          if (rrow) v[e] += rrow[n + e];
+        }
+      }
+    }
+    if (a.c_pre) {
+      float* prow = a.c_pre + m * a.ld_pre;
+      if (evec && (flags & F_PRE_VEC)) {
+        *reinterpret_cast<f32x4*>(prow + n) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < a.N) prow[n + e] = v[e];
+      }
+    }
+    if (a.act == RR_ACT_RELU) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    if (P.drop_thr != 0u) {
+      const uint64_t base = static_cast<uint64_t>(m) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rr_keep(a.drop_seed, base + e, P.drop_thr) ? v[e] * P.keep_scale : 0.f;
+    }
+    if (evec) {
+      *reinterpret_cast<f32x4*>(crow + n) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < a.N) crow[n + e] = v[e];
+    }
+  }
+}
+
+// ======================================================================== weight gradient
+constexpr int WT = 5;               // 5x5 MFMA tiles (80 x 80) per wave
+constexpr int WBN = 160;            // workgroup output tile: 160 (n) x 160 (k), 2x2 waves
+constexpr int WLD = 176;            // LDS row stride (== 16 mod 32 -> ds_read_b32 conflict-free)
+constexpr int WMT = 16;             // rows of M per staged tile
+
+struct WgradParams {
+  rr_wgrad_args a;
+  int k1p;              // segment-2 start column in the extended X (k1 rounded up to 4)
+  int kext;             // k1p + k2 + 1 (last column = ones -> dbias)
+  int nblk_n, nblk_k;   // output tiles
+  int64_t rows_per_chunk;
+  int nchunks;
+  int flags;            // F_A1_VEC (x1), F_A2_VEC (x2), F_SUB_VEC, F_MASK_VEC (mask), F_EPI_VEC (dy)
+  int64_t slab;         // floats per partial slab = N*(k1+k2) + N
+};
+
+__global__ void __launch_bounds__(THREADS) wgrad_kernel(const WgradParams P) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2 * WMT * WLD];
+  const rr_wgrad_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bn = blockIdx.x / P.nblk_k, bk = blockIdx.x % P.nblk_k;
+  const int nb = bn * WBN, kb = bk * WBN;
+  const int64_t mbeg = static_cast<int64_t>(blockIdx.y) * P.rows_per_chunk;
+  int64_t mend = mbeg + P.rows_per_chunk;
+  if (mend > a.M) mend = a.M;
+  const int flags = P.flags;
+  const int K = a.k1 + a.k2;
+
+  // staging: 2 tiles x 16 rows x 40 float4 = 1280 chunks, 5 per thread
+  auto load_chunk_z = [&](int64_t mrow, int col) -> f32x4 {       // dZ[mrow][nb+col .. +3]
+    f32x4 v = f32x4(0.f);
+    const int n = nb + col;
+    if (mrow >= mend || n >= a.N) return v;
+    v = load_chunk(a.dy + mrow * a.ld_dy, n, a.N, flags & F_EPI_VEC);
+    if (a.mask) v = apply_mask(v, load_chunk(a.mask + mrow * a.ld_mask, n, a.N, flags & F_MASK_VEC), a.mask_scale);
+    return v;
+  };
+  auto load_chunk_x = [&](int64_t mrow, int col) -> f32x4 {       // X_ext[mrow][kb+col .. +3]
+    f32x4 v = f32x4(0.f);
+    const int k = kb + col;
+    if (mrow >= mend || k >= P.kext) return v;
+    if (k < P.k1p) {
+      const float* p = nullptr;
+      if (a.x1_idx) {
+        const int32_t j = a.x1_idx[mrow];
+        if (j >= 0) p = a.x1 + static_cast<int64_t>(j) * a.ldx1;
+      } else {
+        p = a.x1 + mrow * a.ldx1;
+      }
+      v = load_chunk(p, k, a.k1, flags & F_A1_VEC);
+      if (a.x1_sub) {
+        const float* sp = nullptr;
+        if (a.x1_sub_idx) {
+          const int32_t j = a.x1_sub_idx[mrow];
+          if (j >= 0) sp = a.x1_sub + static_cast<int64_t>(j) * a.ldx1_sub;
+        } else {
+          sp = a.x1_sub + mrow * a.ldx1_sub;
+        }
+        v = v - load_chunk(sp, k, a.k1, flags & F_SUB_VEC);
+      }
+    } else {
+      const int k2 = k - P.k1p;
+      if (a.k2 > 0) v = load_chunk(a.x2 + mrow * a.ldx2, k2, a.k2, flags & F_A2_VEC);
+      // the ones column (bias gradient) sits right after segment 2
+      const int one = a.k2 - k2;                 // position of the ones column inside this chunk
+      if (one >= 0 && one < 4) v[one] = 1.0f;
+    }
+    return v;
+  };
+  constexpr int CH = 5;
+  auto load_tiles = [&](int64_t mt, f32x4 (&r)[CH]) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int f = i * THREADS + tid;           // 0 .. 1279
+      const int which = f >= 640 ? 1 : 0;
+      const int g = f - which * 640;
+      const int row = g / 40, col = (g - row * 40) * 4;
+      r[i] = which ? load_chunk_x(mt + row, col) : load_chunk_z(mt + row, col);
+    }
+  };
+  auto store_tiles = [&](int buf, const f32x4 (&r)[CH]) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int f = i * THREADS + tid;
+      const int which = f >= 640 ? 1 : 0;
+      const int g = f - which * 640;
+      const int row = g / 40, col = (g - row * 40) * 4;
+      *reinterpret_cast<f32x4*>(&lds[buf][which * WMT * WLD + row * WLD + col]) = r[i];
+    }
+  };
+
+  f32x4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = f32x4(0.f);
+
+  const int wn = (wave >> 1) * (WT * 16), wk = (wave & 1) * (WT * 16);   // wave's corner inside the 160x160 tile
+  const int fr = lane & 15, fq = lane >> 4;
+
+  f32x4 r[CH];
+  const int64_t ntiles = (mend > mbeg) ? (mend - mbeg + WMT - 1) / WMT : 0;
+  if (ntiles > 0) {
+    load_tiles(mbeg, r);
+    store_tiles(0, r);
+  }
+  __syncthreads();
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int cur = static_cast<int>(t & 1);
+    const bool more = t + 1 < ntiles;
+    if (more) load_tiles(mbeg + (t + 1) * WMT, r);
+    const float* Zs = lds[cur];
+    const float* Xs = lds[cur] + WMT * WLD;
+#pragma unroll
+    for (int kk = 0; kk < WMT / 4; ++kk) {
+      float zf[WT], xf[WT];
+      const int row = kk * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        zf[i] = Zs[row * WLD + wn + i * 16 + fr];
+        xf[i] = Xs[row * WLD + wk + i * 16 + fr];
+      }
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(cur ^ 1, r);
+    __syncthreads();
+  }
+
+  // partial slab [chunk][ N*K (dw, row-major) | N (dbias) ]; D[i = n][j = k]: lane -> n = .. + fq*4 + e, k = .. + fr
+  float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(blockIdx.y) * P.slab;
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int kx = kb + wk + j * 16 + fr;       // extended column
+      if (kx >= P.kext) continue;
+      int kreal = -1;                             // -1: dead pad column, -2: ones column
+      if (kx < a.k1) kreal = kx;
+      else if (kx >= P.k1p && kx < P.k1p + a.k2) kreal = a.k1 + (kx - P.k1p);
+      else if (kx == P.k1p + a.k2) kreal = -2;
+      if (kreal == -1) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = nb + wn + i * 16 + fq * 4 + e;
+        if (n >= a.N) continue;
+        if (kreal >= 0) slab[static_cast<int64_t>(n) * K + kreal] = acc[i][j][e];
+        else slab[static_cast<int64_t>(a.N) * K + n] = acc[i][j][e];
+      }
+    }
+  }
+}
+
+// fixed-order sum of the chunk slabs into dw / dbias
+__global__ void __launch_bounds__(THREADS) wgrad_reduce_kernel(const float* __restrict__ ws, int nchunks, int64_t slab,
+                                                               int N, int K, float* __restrict__ dw, int64_t ld_dw,
+                                                               float* __restrict__ dbias, int accumulate) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= slab) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    s0 += ws[static_cast<int64_t>(c) * slab + e];
+    s1 += ws[static_cast<int64_t>(c + 1) * slab + e];
+    s2 += ws[static_cast<int64_t>(c + 2) * slab + e];
+    s3 += ws[static_cast<int64_t>(c + 3) * slab + e];
+  }
+  for (; c < nchunks; ++c) s0 += ws[static_cast<int64_t>(c) * slab + e];
+  const float s = (s0 + s1) + (s2 + s3);
+  const int64_t nk = static_cast<int64_t>(N) * K;
+  if (e < nk) {
+    const int64_t n = e / K, k = e - n * K;
+    float* d = dw + n * ld_dw + k;
+    *d = accumulate ? *d + s : s;
+  } else if (dbias) {
+    float* d = dbias + (e - nk);
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+int64_t wgrad_want_chunks(int64_t M, int N, int kext) {
+  const int tiles = ((N + WBN - 1) / WBN) * ((kext + WBN - 1) / WBN);
+  int64_t want = (512 + tiles - 1) / tiles;       // ~512 workgroups: 2 per CU
+  const int64_t maxc = (M + 63) / 64;
+  if (want > maxc) want = maxc;
+  if (want < 1) want = 1;
+  return want;
+}
+
+void wgrad_plan(int64_t M, int N, int k1, int k2, WgradParams* P) {
+  P->k1p = (k1 + 3) & ~3;                         // segment 2 (and the ones column) start 16-byte aligned
+  P->kext = P->k1p + k2 + 1;
+  P->nblk_n = (N + WBN - 1) / WBN;
+  P->nblk_k = (P->kext + WBN - 1) / WBN;
+  const int64_t want = wgrad_want_chunks(M, N, P->kext);
+  int64_t rpc = (M + want - 1) / want;
+  rpc = (rpc + WMT - 1) / WMT * WMT;
+  if (rpc < WMT) rpc = WMT;
+  P->rows_per_chunk = rpc;
+  P->nchunks = static_cast<int>((M + rpc - 1) / rpc);
+  if (P->nchunks < 1) P->nchunks = 1;
+  P->slab = static_cast<int64_t>(N) * (k1 + k2) + N;
+}
+
+template <int NT>
+int launch_linear(const LinearParams& P, hipStream_t s) {
+  const rr_linear_args& a = P.a;
+  dim3 grid(static_cast<unsigned>((a.M + BM - 1) / BM), static_cast<unsigned>((a.N + 16 * NT - 1) / (16 * NT)));
+  if (a.a_mask) linear_kernel<NT, 2><<<grid, THREADS, 0, s>>>(P);
+  else if (a.a1_sub) linear_kernel<NT, 1><<<grid, THREADS, 0, s>>>(P);
+  else linear_kernel<NT, 0><<<grid, THREADS, 0, s>>>(P);
+  return rr_launch_status();
+}
+
+inline bool vec_ok(const float* p, int64_t ld) { return p && rr_aligned16(p) && (ld % 4 == 0); }
+
+}  // namespace
+
+extern "C" {
+
+int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
+  RR_CHECK_ARG(args);
+  const rr_linear_args& a = *args;
+  RR_CHECK_ARG(a.M >= 0 && a.N >= 1 && a.k1 >= 0 && a.k2 >= 0 && a.k1 + a.k2 >= 1);
+  RR_CHECK_ARG(a.w && a.c && a.ldw >= a.k1 + a.k2 && a.ldc >= a.N);
+  RR_CHECK_ARG(a.k1 == 0 || (a.a1 && a.lda1 >= a.k1));
+  RR_CHECK_ARG(a.k2 == 0 || (a.a2 && a.lda2 >= a.k2));
+  RR_CHECK_ARG(!a.a1_sub || (a.k1 > 0 && a.lda1_sub >= a.k1));
+  RR_CHECK_ARG(!a.a_mask || (a.k2 == 0 && !a.a1_sub && !a.a1_idx && a.ld_mask >= a.k1));
+  RR_CHECK_ARG(!a.residual || a.ldr >= a.N);
+  RR_CHECK_ARG(!a.c_pre || a.ld_pre >= a.N);
+  RR_CHECK_ARG(a.act == RR_ACT_NONE || a.act == RR_ACT_RELU);
+  RR_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f);
+  RR_CHECK_ARG(a.M < (int64_t(1) << 31) * BM);
+  if (a.M == 0) return RR_OK;
+
+  LinearParams P;
+  P.a = a;
+  P.t1 = (a.k1 + BK - 1) / BK;
+  P.t2 = (a.k2 + BK - 1) / BK;
+  P.flags = 0;
+  if (a.k1 > 0 && vec_ok(a.a1, a.lda1)) P.flags |= F_A1_VEC;
+  if (a.k2 > 0 && vec_ok(a.a2, a.lda2)) P.flags |= F_A2_VEC;
+  if (a.a1_sub && vec_ok(a.a1_sub, a.lda1_sub)) P.flags |= F_SUB_VEC;
+  if (a.a_mask && vec_ok(a.a_mask, a.ld_mask)) P.flags |= F_MASK_VEC;
+  if (vec_ok(a.w, a.ldw)) {
+    P.flags |= F_W1_VEC;
+    if (a.k1 % 4 == 0) P.flags |= F_W2_VEC;
+  }
+  if (a.N % 4 == 0 && vec_ok(a.c, a.ldc) && (!a.bias || rr_aligned16(a.bias)) &&
+      (!a.residual || vec_ok(a.residual, a.ldr)))
+    P.flags |= F_EPI_VEC;
+  if (a.c_pre && vec_ok(a.c_pre, a.ld_pre)) P.flags |= F_PRE_VEC;
+  P.drop_thr = rr_drop_threshold(a.drop_p);
+  P.keep_scale = 1.0f / (1.0f - a.drop_p);
+
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.N <= 64) return launch_linear<4>(P, s);
+  if (a.N <= 160) return launch_linear<10>(P, s);
+  return launch_linear<19>(P, s);
+}
+
+size_t rr_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
+  if (M < 0 || N < 1 || K < 1) return 0;
+  // upper bound over every [k1|k2] split of K: the chunk count is largest for the narrowest extended K
+  const int64_t nc = wgrad_want_chunks(M, N, K + 1);
+  return static_cast<size_t>(nc) * (static_cast<size_t>(N) * K + N) * sizeof(float);
+}
+
+int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
+  RR_CHECK_ARG(args);
+  const rr_wgrad_args& a = *args;
+  RR_CHECK_ARG(a.M >= 0 && a.N >= 1 && a.k1 >= 0 && a.k2 >= 0 && a.k1 + a.k2 >= 1);
+  RR_CHECK_ARG(a.dy && a.dw && a.workspace && a.ld_dy >= a.N && a.ld_dw >= a.k1 + a.k2);
+  RR_CHECK_ARG(a.k1 == 0 || (a.x1 && a.ldx1 >= a.k1));
+  RR_CHECK_ARG(a.k2 == 0 || (a.x2 && a.ldx2 >= a.k2));
+  RR_CHECK_ARG(!a.x1_sub || (a.k1 > 0 && a.ldx1_sub >= a.k1));
+  RR_CHECK_ARG(!a.mask || a.ld_mask >= a.N);
+  const int K = a.k1 + a.k2;
+  WgradParams P;
+  P.a = a;
+  wgrad_plan(a.M, a.N, a.k1, a.k2, &P);
+  if (a.workspace_bytes < static_cast<size_t>(P.nchunks) * static_cast<size_t>(P.slab) * sizeof(float))
+    return RR_ERR_WORKSPACE;
+  P.flags = 0;
+  if (a.k1 > 0 && vec_ok(a.x1, a.ldx1)) P.flags |= F_A1_VEC;
+  if (a.k2 > 0 && vec_ok(a.x2, a.ldx2)) P.flags |= F_A2_VEC;
+  if (a.x1_sub && vec_ok(a.x1_sub, a.ldx1_sub)) P.flags |= F_SUB_VEC;
+  if (a.mask && vec_ok(a.mask, a.ld_mask)) P.flags |= F_MASK_VEC;
+  if (vec_ok(a.dy, a.ld_dy)) P.flags |= F_EPI_VEC;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(static_cast<unsigned>(P.nblk_n * P.nblk_k), static_cast<unsigned>(P.nchunks));
+  wgrad_kernel<<<grid, THREADS, 0, s>>>(P);
+  const int64_t total = P.slab;
+  wgrad_reduce_kernel<<<static_cast<unsigned>((total + THREADS - 1) / THREADS), THREADS, 0, s>>>(
+      static_cast<const float*>(a.workspace), P.nchunks, P.slab, a.N, K, a.dw, a.ld_dw, a.dbias, a.accumulate);
+  return rr_launch_status();
+}
+
+}  // extern "C"

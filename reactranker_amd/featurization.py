@@ -1,0 +1,304 @@
+"""Graph batching for the HIP path — host-side mirror of the reference's
+`reactranker/features/featurization.py` (BatchMolGraph :231-335, MolGraph :135-210).
+
+`BatchMolGraph` keeps the reference's attributes and accessors (`get_components()`,
+`get_a2a()`, `a_scope`, `max_num_bonds`, ...) but is built by the native packer
+(`rr_pack_graphs`, csrc/pack.cpp) instead of Python list appends, uses int32 indices and
+16-byte aligned feature rows, and also carries the transposed index tables the backward
+kernels need.  `DeviceGraph` is its resident-in-HBM form; it is uploaded once per batch
+object and cached (the reference re-copies five tensors per forward, models/mpn.py:77).
+
+SMILES featurisation itself (RDKit) is out of scope: molecules
+enter as `synth.MolSpec` arrays or as any object with the reference MolGraph's attributes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synth import ATOM_FDIM, BOND_FDIM, MolSpec
+
+FA_LD = 64     # f_atoms row stride (61 -> 64 floats, 16-byte aligned rows)
+FB_LD = 84     # f_bonds row stride (83 -> 84)
+
+
+def get_atom_fdim() -> int:
+    return ATOM_FDIM
+
+
+def get_bond_fdim() -> int:
+    return BOND_FDIM
+
+
+class MolGraph:
+    """Single-molecule graph (reference featurization.py:135-210) backed by arrays.
+
+    Build with `MolGraph.from_spec(spec)`; constructing from a SMILES string needs RDKit,
+    which this environment does not have.
+    """
+
+    def __init__(self, smiles: str = None, reaction: bool = True, atom_messages: bool = False, *, spec: MolSpec = None):
+        if spec is None:
+            raise RuntimeError("MolGraph(smiles) needs RDKit featurisation, which is outside the HIP hot path; "
+                               "use MolGraph.from_spec(MolSpec) or pass reference MolGraph objects")
+        self.spec = spec
+        self.smiles = spec.smiles if smiles is None else smiles
+        self.n_atoms = spec.n_atoms
+        self.n_bonds = spec.n_bonds
+
+    @classmethod
+    def from_spec(cls, spec: MolSpec) -> "MolGraph":
+        return cls(spec=spec)
+
+
+def _concat_specs(specs: Sequence[MolSpec]):
+    """Vectorised MolGraph construction for a whole batch of MolSpecs (no per-bond python)."""
+    M = len(specs)
+    mol_atoms = np.fromiter((s.n_atoms for s in specs), dtype=np.int32, count=M)
+    n_edges = np.fromiter((s.edges.shape[0] for s in specs), dtype=np.int64, count=M)
+    mol_bonds = (2 * n_edges).astype(np.int32)
+    f_atoms_cat = np.concatenate([s.f_atoms for s in specs], axis=0).astype(np.float32, copy=False) if M else \
+        np.zeros((0, ATOM_FDIM), np.float32)
+    edges = np.concatenate([s.edges for s in specs], axis=0).astype(np.int64) if M else np.zeros((0, 2), np.int64)
+    fbond = np.concatenate([s.f_bond for s in specs], axis=0).astype(np.float32, copy=False) if M else \
+        np.zeros((0, BOND_FDIM), np.float32)
+    E = edges.shape[0]
+    atom_off = np.concatenate([[0], np.cumsum(mol_atoms, dtype=np.int64)])
+    edge_off = np.concatenate([[0], np.cumsum(n_edges)])
+    mol_of_edge = np.repeat(np.arange(M), n_edges)
+    e_local = np.arange(E) - edge_off[mol_of_edge]
+    # directed bonds, reference numbering: b1 = a1->a2 (even), b2 = a2->a1 (odd)  featurization.py:202-210
+    b2a_local = np.empty(2 * E, np.int32)
+    b2a_local[0::2] = edges[:, 0]
+    b2a_local[1::2] = edges[:, 1]
+    b2revb_local = np.empty(2 * E, np.int32)
+    b2revb_local[0::2] = 2 * e_local + 1
+    b2revb_local[1::2] = 2 * e_local
+    src_global = np.empty(2 * E, np.int64)
+    src_global[0::2] = edges[:, 0] + atom_off[mol_of_edge]
+    src_global[1::2] = edges[:, 1] + atom_off[mol_of_edge]
+    tgt_global = np.empty(2 * E, np.int64)
+    tgt_global[0::2] = src_global[1::2]
+    tgt_global[1::2] = src_global[0::2]
+    f_bonds_cat = np.empty((2 * E, ATOM_FDIM + BOND_FDIM), np.float32)
+    f_bonds_cat[:, :ATOM_FDIM] = f_atoms_cat[src_global]                 # f_atoms[src] ++ f_bond, :198-199
+    f_bonds_cat[0::2, ATOM_FDIM:] = fbond
+    f_bonds_cat[1::2, ATOM_FDIM:] = fbond
+    # incoming-bond lists in increasing bond order (a2b[a2].append(b1), a2b[a1].append(b2))
+    order = np.argsort(tgt_global, kind="stable")
+    bond_local = np.empty(2 * E, np.int32)
+    bond_local[0::2] = 2 * e_local
+    bond_local[1::2] = 2 * e_local + 1
+    a2b_local = bond_local[order]
+    total_atoms = int(atom_off[-1])
+    counts = np.bincount(tgt_global, minlength=total_atoms).astype(np.int64)
+    a2b_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return mol_atoms, mol_bonds, f_atoms_cat, f_bonds_cat, b2a_local, b2revb_local, a2b_off, a2b_local
+
+
+def _concat_ducks(graphs):
+    """Same arrays from reference-style MolGraph objects (python lists)."""
+    M = len(graphs)
+    mol_atoms = np.array([g.n_atoms for g in graphs], np.int32)
+    mol_bonds = np.array([g.n_bonds for g in graphs], np.int32)
+    fa = [np.asarray(g.f_atoms, np.float32).reshape(g.n_atoms, -1) for g in graphs]
+    fb = [np.asarray(g.f_bonds, np.float32).reshape(g.n_bonds, -1) for g in graphs]
+    f_atoms_cat = np.concatenate(fa, 0) if M else np.zeros((0, ATOM_FDIM), np.float32)
+    f_bonds_cat = np.concatenate(fb, 0) if M else np.zeros((0, ATOM_FDIM + BOND_FDIM), np.float32)
+    b2a_local = np.concatenate([np.asarray(g.b2a, np.int32) for g in graphs]) if M else np.zeros(0, np.int32)
+    b2revb_local = np.concatenate([np.asarray(g.b2revb, np.int32) for g in graphs]) if M else np.zeros(0, np.int32)
+    lens, vals = [], []
+    for g in graphs:
+        for lst in g.a2b:
+            lens.append(len(lst))
+            vals.extend(lst)
+    a2b_off = np.concatenate([[0], np.cumsum(np.asarray(lens, np.int64))]).astype(np.int64)
+    a2b_local = np.asarray(vals, np.int32)
+    return mol_atoms, mol_bonds, f_atoms_cat, f_bonds_cat, b2a_local, b2revb_local, a2b_off, a2b_local
+
+
+class DeviceGraph:
+    """A packed batch resident in HBM: features, index arrays and backward tables."""
+
+    __slots__ = ("device", "nA", "nB", "K", "M", "f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope",
+                 "a2b_rev_t", "b2t", "a2a_t", "npad", "atom2mol", "_fb_sum", "bytes")
+
+    def __init__(self, host: dict, device):
+        self.device = torch.device(device)
+        self.nA, self.nB, self.K, self.M = host["nA"], host["nB"], host["K"], host["M"]
+        self.bytes = 0
+        for k in ("f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope", "a2b_rev_t", "b2t", "a2a_t", "npad",
+                  "atom2mol"):
+            t = torch.from_numpy(host[k]).to(self.device, non_blocking=False)
+            setattr(self, k, t)
+            self.bytes += t.numel() * t.element_size()
+        self._fb_sum = None
+
+    def fb_sum(self):
+        """sum_k f_bonds[a2b[a,k]]  ([nA, 84]) — the bond-feature half of MPNDiff's neighbour sum
+        (reference models/mpn.py:202-209).  Input-only, so it is computed once per batch and cached."""
+        if self._fb_sum is None:
+            from . import functions as Fn
+            self._fb_sum = Fn.gather_sum(self.f_bonds, self.a2b, BOND_FDIM + ATOM_FDIM)
+        return self._fb_sum
+
+
+def _pack(arrs, K_override: int) -> dict:
+    mol_atoms, mol_bonds, f_atoms_cat, f_bonds_cat, b2a_local, b2revb_local, a2b_off, a2b_local = arrs
+    L = _lib.lib()
+    M = int(mol_atoms.shape[0])
+    nA, nB, K = C.c_int64(), C.c_int64(), C.c_int32()
+    mol_atoms = np.ascontiguousarray(mol_atoms, np.int32)
+    mol_bonds = np.ascontiguousarray(mol_bonds, np.int32)
+    a2b_off = np.ascontiguousarray(a2b_off, np.int64)
+    _lib.check(L.rr_pack_sizes(_lib.np_ptr(mol_atoms), _lib.np_ptr(mol_bonds), M, _lib.np_ptr(a2b_off), int(K_override),
+                               C.byref(nA), C.byref(nB), C.byref(K)), "rr_pack_sizes")
+    nA, nB, K = int(nA.value), int(nB.value), int(K.value)
+    atom_fdim = int(f_atoms_cat.shape[1]) if f_atoms_cat.ndim == 2 and f_atoms_cat.shape[1] else ATOM_FDIM
+    bond_fdim = int(f_bonds_cat.shape[1]) if f_bonds_cat.ndim == 2 and f_bonds_cat.shape[1] else ATOM_FDIM + BOND_FDIM
+    ld_fa = (atom_fdim + 3) // 4 * 4
+    ld_fb = (bond_fdim + 3) // 4 * 4
+    out = dict(
+        f_atoms=np.empty((nA, ld_fa), np.float32), f_bonds=np.empty((nB, ld_fb), np.float32),
+        a2b=np.empty((nA, K), np.int32), b2a=np.empty(nB, np.int32), b2revb=np.empty(nB, np.int32),
+        a2a=np.empty((nA, K), np.int32), a_scope=np.empty((M, 2), np.int32),
+        a2b_rev_t=np.empty((nA, K), np.int32), b2t=np.empty(nB, np.int32), a2a_t=np.empty((nA, K), np.int32),
+        npad=np.empty(nA, np.float32), atom2mol=np.empty(nA, np.int32))
+    f_atoms_cat = np.ascontiguousarray(f_atoms_cat, np.float32)
+    f_bonds_cat = np.ascontiguousarray(f_bonds_cat, np.float32)
+    b2a_local = np.ascontiguousarray(b2a_local, np.int32)
+    b2revb_local = np.ascontiguousarray(b2revb_local, np.int32)
+    a2b_local = np.ascontiguousarray(a2b_local, np.int32)
+    _lib.check(L.rr_pack_graphs(
+        _lib.np_ptr(mol_atoms), _lib.np_ptr(mol_bonds), M, _lib.np_ptr(f_atoms_cat), atom_fdim,
+        _lib.np_ptr(f_bonds_cat), bond_fdim, _lib.np_ptr(b2a_local), _lib.np_ptr(b2revb_local),
+        _lib.np_ptr(a2b_off), _lib.np_ptr(a2b_local), K,
+        _lib.np_ptr(out["f_atoms"]), ld_fa, _lib.np_ptr(out["f_bonds"]), ld_fb,
+        _lib.np_ptr(out["a2b"]), _lib.np_ptr(out["b2a"]), _lib.np_ptr(out["b2revb"]), _lib.np_ptr(out["a2a"]),
+        _lib.np_ptr(out["a_scope"]), _lib.np_ptr(out["a2b_rev_t"]), _lib.np_ptr(out["b2t"]),
+        _lib.np_ptr(out["a2a_t"]), _lib.np_ptr(out["npad"]), _lib.np_ptr(out["atom2mol"])), "rr_pack_graphs")
+    out.update(nA=nA, nB=nB, K=K, M=M, atom_fdim=atom_fdim, bond_fdim=bond_fdim)
+    return out
+
+
+class BatchMolGraph:
+    """Drop-in for the reference BatchMolGraph (features/featurization.py:231-335)."""
+
+    def __init__(self, mol_graphs: Sequence, atom_messages: bool = False, K: Optional[int] = None):
+        if atom_messages:
+            raise NotImplementedError("atom_messages=True is never used on the reference's reaction path")
+        graphs = list(mol_graphs)
+        self.smiles_batch = [getattr(g, "smiles", "") for g in graphs]
+        self.n_mols = len(graphs)
+        self.atom_fdim = get_atom_fdim()
+        self.bond_fdim = get_bond_fdim() + self.atom_fdim
+        specs = [g.spec if isinstance(g, MolGraph) else g for g in graphs]
+        if all(isinstance(s, MolSpec) for s in specs):
+            arrs = _concat_specs(specs)
+        else:
+            arrs = _concat_ducks(specs)
+        self._host = _pack(arrs, 0 if K is None else int(K))
+        h = self._host
+        self.n_atoms, self.n_bonds = h["nA"], h["nB"]
+        self.max_num_bonds = h["K"]
+        self.a_scope: List[Tuple[int, int]] = [tuple(int(v) for v in r) for r in h["a_scope"]]
+        boff = np.concatenate([[1], 1 + np.cumsum(arrs[1], dtype=np.int64)])
+        self.b_scope: List[Tuple[int, int]] = [(int(boff[i]), int(arrs[1][i])) for i in range(self.n_mols)]
+        self.b2b = None
+        self._dev = {}
+
+    # ---- reference-typed views (FloatTensor / LongTensor on the host) -------------------------------
+    @property
+    def f_atoms(self):
+        return torch.from_numpy(np.ascontiguousarray(self._host["f_atoms"][:, :self._host["atom_fdim"]]))
+
+    @property
+    def f_bonds(self):
+        return torch.from_numpy(np.ascontiguousarray(self._host["f_bonds"][:, :self._host["bond_fdim"]]))
+
+    @property
+    def a2b(self):
+        return torch.from_numpy(self._host["a2b"].astype(np.int64))
+
+    @property
+    def b2a(self):
+        return torch.from_numpy(self._host["b2a"].astype(np.int64))
+
+    @property
+    def b2revb(self):
+        return torch.from_numpy(self._host["b2revb"].astype(np.int64))
+
+    @property
+    def a2a(self):
+        return torch.from_numpy(self._host["a2a"].astype(np.int64))
+
+    def get_components(self):
+        return self.f_atoms, self.f_bonds, self.a2b, self.b2a, self.b2revb, self.a_scope, self.b_scope
+
+    def get_a2a(self):
+        return self.a2a
+
+    def get_smiles(self):
+        return self.smiles_batch
+
+    # ---- HBM-resident form --------------------------------------------------------------------------
+    def device_graph(self, gpu) -> DeviceGraph:
+        dev = torch.device("cuda", torch.cuda.current_device() if gpu is None else int(gpu)) \
+            if not isinstance(gpu, torch.device) else gpu
+        key = str(dev)
+        if key not in self._dev:
+            self._dev[key] = DeviceGraph(self._host, dev)
+        return self._dev[key]
+
+
+def device_graph_of(batch, gpu) -> DeviceGraph:
+    """DeviceGraph for our BatchMolGraph, or for any object exposing the reference's
+    get_components()/get_a2a() contract (e.g. the reference's own BatchMolGraph)."""
+    if isinstance(batch, DeviceGraph):
+        return batch
+    if isinstance(batch, BatchMolGraph):
+        return batch.device_graph(gpu)
+    cache = getattr(batch, "_rr_device_graphs", None)
+    if cache is None:
+        cache = {}
+        try:
+            batch._rr_device_graphs = cache
+        except AttributeError:
+            pass
+    dev = torch.device("cuda", torch.cuda.current_device() if gpu is None else int(gpu))
+    key = str(dev)
+    if key in cache:
+        return cache[key]
+    f_atoms, f_bonds, a2b, b2a, b2revb, a_scope, _ = batch.get_components()
+    fa = np.asarray(f_atoms, np.float32)
+    fb = np.asarray(f_bonds, np.float32)
+    a2b_np = np.ascontiguousarray(np.asarray(a2b), np.int32)
+    b2a_np = np.ascontiguousarray(np.asarray(b2a), np.int32)
+    b2revb_np = np.ascontiguousarray(np.asarray(b2revb), np.int32)
+    nA, K = a2b_np.shape
+    nB = b2a_np.shape[0]
+    scope = np.ascontiguousarray(np.asarray(a_scope, np.int32).reshape(-1, 2))
+    M = scope.shape[0]
+    ld_fa, ld_fb = (fa.shape[1] + 3) // 4 * 4, (fb.shape[1] + 3) // 4 * 4
+    host = dict(f_atoms=np.zeros((nA, ld_fa), np.float32), f_bonds=np.zeros((nB, ld_fb), np.float32),
+                a2b=a2b_np, b2a=b2a_np, b2revb=b2revb_np, a2a=np.empty((nA, K), np.int32), a_scope=scope,
+                a2b_rev_t=np.empty((nA, K), np.int32), b2t=np.empty(nB, np.int32), a2a_t=np.empty((nA, K), np.int32),
+                npad=np.empty(nA, np.float32), atom2mol=np.empty(nA, np.int32), nA=nA, nB=nB, K=K, M=M)
+    host["f_atoms"][:, :fa.shape[1]] = fa
+    host["f_bonds"][:, :fb.shape[1]] = fb
+    _lib.check(_lib.lib().rr_derive_tables(
+        _lib.np_ptr(a2b_np), _lib.np_ptr(b2a_np), _lib.np_ptr(b2revb_np), nA, nB, K, _lib.np_ptr(scope), M,
+        _lib.np_ptr(host["a2a"]), _lib.np_ptr(host["a2b_rev_t"]), _lib.np_ptr(host["b2t"]),
+        _lib.np_ptr(host["a2a_t"]), _lib.np_ptr(host["npad"]), _lib.np_ptr(host["atom2mol"])), "rr_derive_tables")
+    dg = DeviceGraph(host, dev)
+    cache[key] = dg
+    return dg
+
+
+def mol2graph(smiles_batch):
+    """Reference featurization.py:338-350 — needs RDKit."""
+    return BatchMolGraph([MolGraph(s) for s in smiles_batch])

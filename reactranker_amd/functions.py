@@ -1,0 +1,539 @@
+"""Op wrappers + the hand-written forward/backward of the reaction scorer.
+
+Layer 1: thin wrappers that launch one C-ABI entry point on torch device tensors
+         (pointers, sizes and the current HIP stream go straight to the library).
+Layer 2: the encoder / diff-encoder / FFN forward and backward passes, written against
+         layer 1 only — the backward is explicit (no autograd graph of tiny ops): every
+         gather-sum's adjoint is a gather-sum over the packer's transposed tables, weight
+         gradients are split-M MFMA GEMMs with a fixed-order reduction.
+Layer 3: torch.autograd.Function shells so the nn.Modules behave like the reference's.
+
+Reference sites are cited per function (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import LinearArgs, WgradArgs, check, lib, ptr, stream
+
+ACT_NONE, ACT_RELU = 0, 1
+ATOM_FDIM, BOND_FDIM = 61, 22
+FBOND = ATOM_FDIM + BOND_FDIM      # 83: width of an f_bonds row
+
+HEADS = {  # FFN task_type string -> rr_head (reference models/base_model.py:61-106)
+    "evidential_with_softplus": 6, "gauss_regression_with_softplus": 4, "gaussian_with_softplus": 4,
+    "listnetdis_lognorm_with_softplus": 5, "evidential_ranking": 3, "listnet_with_softplus": 1,
+    "listnet_with_uncertainty": 2, "evidential": 2,
+}
+
+
+def _rowmajor(t: torch.Tensor, name: str) -> torch.Tensor:
+    """float32 CUDA tensor whose rows are contiguous (row stride >= row length); copies otherwise
+    (e.g. the stride-0 expanded gradients autograd hands to backward)."""
+    _lib.require_cuda(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    if t.dim() == 2:
+        if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+            t = t.contiguous()
+    elif not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: Optional[torch.Tensor]) -> int:
+    if t is None:
+        return 0
+    return t.stride(0) if t.dim() == 2 else t.numel()
+
+
+def _new(like: torch.Tensor, *shape) -> torch.Tensor:
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+# =========================================================================== layer 1
+def gather_sum(src: torch.Tensor, idx: torch.Tensor, H: int, out: torch.Tensor = None) -> torch.Tensor:
+    """out[r] = sum_k src[idx[r,k]] — index_select_ND + sum(dim=1) (utils.py:176-193; models/mpn.py:89-90)."""
+    n_out, K = (idx.shape[0], idx.shape[1]) if idx.dim() == 2 else (idx.shape[0], 1)
+    if out is None:
+        out = _new(src, n_out, H)
+    check(lib().rr_gather_sum_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), n_out, K, H, ptr(out), _ld(out),
+                                  stream()), "rr_gather_sum_f32")
+    return out
+
+
+def gather_diff(a, ia, m, im, H: int, out=None):
+    """out[r] = a[ia[r]] - m[im[r]] (models/mpn.py:91-92)."""
+    n_out = ia.shape[0]
+    if out is None:
+        out = _new(a, n_out, H)
+    check(lib().rr_gather_diff_f32(ptr(a), a.shape[0], _ld(a), ptr(ia), ptr(m), m.shape[0], _ld(m), ptr(im), n_out, H,
+                                   ptr(out), _ld(out), stream()), "rr_gather_diff_f32")
+    return out
+
+
+def weighted_colsum(x, w, H: int, out, accumulate: bool):
+    """out[0:H] (+)= sum_r w[r] x[r]; the padding row's adjoint."""
+    n = x.shape[0]
+    nbytes = lib().rr_colsum_workspace_bytes(n, H)
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=x.device)
+    check(lib().rr_weighted_colsum_f32(ptr(x), n, _ld(x), ptr(w), H, ptr(out), int(accumulate), ptr(ws), nbytes,
+                                       stream()), "rr_weighted_colsum_f32")
+    return out
+
+
+def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub_idx=None, a2=None, k2=0, a_mask=None,
+           mask_scale=1.0, ldw=None, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, out=None, c_pre=None):
+    """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h)."""
+    ref = a1 if a1 is not None else a2
+    if out is None:
+        out = _new(ref, M, N)
+    A = LinearArgs()
+    A.M, A.N = M, N
+    A.a1, A.lda1, A.k1, A.a1_idx = ptr(a1), _ld(a1), k1, ptr(a1_idx)
+    A.a1_sub, A.lda1_sub, A.a1_sub_idx = ptr(a1_sub), _ld(a1_sub), ptr(a1_sub_idx)
+    A.a2, A.lda2, A.k2 = ptr(a2), _ld(a2), k2
+    A.a_mask, A.ld_mask, A.mask_scale = ptr(a_mask), _ld(a_mask), float(mask_scale)
+    A.w, A.ldw = ptr(w), (w.stride(0) if ldw is None else ldw)
+    A.bias = ptr(bias)
+    A.residual, A.ldr = ptr(residual), _ld(residual)
+    A.act, A.drop_p, A.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
+    A.c, A.ldc = ptr(out), _ld(out)
+    A.c_pre, A.ld_pre = ptr(c_pre), _ld(c_pre)
+    check(lib().rr_linear_f32(C.byref(A), stream()), "rr_linear_f32")
+    return out
+
+
+def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=None, k1=0, x1_idx=None, x1_sub=None,
+          x1_sub_idx=None, x2=None, k2=0, accumulate=False, ld_dw=None):
+    """dw (+)= dZ^T [X1|X2], dbias (+)= colsum(dZ) with dZ = dy * (mask > 0) * mask_scale."""
+    K = k1 + k2
+    nbytes = lib().rr_linear_wgrad_workspace_bytes(M, N, K)
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dy.device)
+    A = WgradArgs()
+    A.M, A.N = M, N
+    A.dy, A.ld_dy = ptr(dy), _ld(dy)
+    A.mask, A.ld_mask, A.mask_scale = ptr(mask), _ld(mask), float(mask_scale)
+    A.x1, A.ldx1, A.k1, A.x1_idx = ptr(x1), _ld(x1), k1, ptr(x1_idx)
+    A.x1_sub, A.ldx1_sub, A.x1_sub_idx = ptr(x1_sub), _ld(x1_sub), ptr(x1_sub_idx)
+    A.x2, A.ldx2, A.k2 = ptr(x2), _ld(x2), k2
+    A.dw, A.ld_dw = ptr(dw), (dw.stride(0) if ld_dw is None else ld_dw)
+    A.dbias = ptr(dbias)
+    A.accumulate = int(accumulate)
+    A.workspace, A.workspace_bytes = ptr(ws), nbytes
+    check(lib().rr_linear_wgrad_f32(C.byref(A), stream()), "rr_linear_wgrad_f32")
+    return dw
+
+
+def relu_bwd(dy, y, scale: float, dz=None, acc=None):
+    if dz is None:
+        dz = torch.empty_like(y)
+    check(lib().rr_relu_bwd_f32(ptr(dy), ptr(y), float(scale), ptr(dz), ptr(acc), y.numel(), stream()),
+          "rr_relu_bwd_f32")
+    return dz
+
+
+def axpby(alpha: float, a, beta: float = 0.0, b=None, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().rr_axpby_f32(float(alpha), ptr(a), float(beta), ptr(b), ptr(out), a.numel(), stream()), "rr_axpby_f32")
+    return out
+
+
+def dropout(x, p: float, seed: int, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().rr_dropout_f32(ptr(x), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(out), stream()),
+          "rr_dropout_f32")
+    return out
+
+
+def segment_mean_fwd(x, g, H: int, feat, F: int, drop_p: float, seed: int):
+    out = _new(x, g.M, H + F)
+    check(lib().rr_segment_mean_fwd_f32(ptr(x), _ld(x), ptr(g.a_scope), g.M, H, ptr(feat), F, float(drop_p),
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(out), _ld(out), stream()),
+          "rr_segment_mean_fwd_f32")
+    return out
+
+
+def segment_mean_bwd(dout, g, H: int, F: int, drop_p: float, seed: int):
+    dx = _new(dout, g.nA, H)
+    check(lib().rr_segment_mean_bwd_f32(ptr(dout), _ld(dout), ptr(g.a_scope), ptr(g.atom2mol), g.nA, H, F,
+                                        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(dx), _ld(dx), stream()),
+          "rr_segment_mean_bwd_f32")
+    return dx
+
+
+def head_fwd(raw, head: int):
+    out = torch.empty_like(raw)
+    check(lib().rr_head_fwd_f32(ptr(raw), raw.shape[0], raw.shape[1], head, ptr(out), stream()), "rr_head_fwd_f32")
+    return out
+
+
+def head_bwd(dout, raw, head: int):
+    draw = torch.empty_like(raw)
+    check(lib().rr_head_bwd_f32(ptr(dout), ptr(raw), raw.shape[0], raw.shape[1], head, ptr(draw), stream()),
+          "rr_head_bwd_f32")
+    return draw
+
+
+# =========================================================================== layer 2
+class LinW:
+    """One nn.Linear's tensors plus lazily transposed copies for the input-gradient GEMM."""
+
+    def __init__(self, weight, bias):
+        self.w = None if weight is None else _rowmajor(weight.detach(), "weight")
+        self.b = None if bias is None else _rowmajor(bias.detach(), "bias")
+        self._t = {}
+
+    def t(self, c0: int, c1: int):
+        """(W[:, c0:c1])^T, contiguous [c1-c0, N] — the `w` of dX = dZ * W."""
+        key = (c0, c1)
+        if key not in self._t:
+            self._t[key] = self.w[:, c0:c1].t().contiguous()
+        return self._t[key]
+
+    def grads(self):
+        gw = torch.empty_like(self.w)
+        gb = None if self.b is None else torch.empty_like(self.b)
+        return gw, gb
+
+
+def _site_seed(seed: int, site: int) -> int:
+    return (int(seed) * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def mpn_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p: float, seed: int):
+    """MPN.forward, return_atom_hiddens=True (models/mpn.py:61-108) -> (atom_hiddens [nA,H], saved)."""
+    nA, nB = g.nA, g.nB
+    inp = _new(g.f_bonds, nB, H)
+    msg = _new(g.f_bonds, nB, H)
+    linear(nB, H, Wi.w, a1=g.f_bonds, k1=FBOND, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp)          # :80-81
+    msgs, amsgs = [msg], []
+    for it in range(depth - 1):                                                                      # :84
+        a_msg = gather_sum(msgs[-1], g.a2b, H)                                                       # :89-90
+        new = linear(nB, H, Wh.w, a1=a_msg, k1=H, a1_idx=g.b2a, a1_sub=msgs[-1], a1_sub_idx=g.b2revb,
+                     bias=Wh.b, residual=inp, act=ACT_RELU, drop_p=p, seed=_site_seed(seed, it))     # :91-97
+        amsgs.append(a_msg)
+        msgs.append(new)
+    del inp
+    a_last = gather_sum(msgs[-1], g.a2b, H)                                                          # :101-102
+    h = linear(nA, H, Wo.w, a1=g.f_atoms, k1=ATOM_FDIM, a2=a_last, k2=H, bias=Wo.b, act=ACT_RELU, drop_p=p,
+               seed=_site_seed(seed, 1000))                                                          # :103-105
+    return h, (msgs, amsgs, a_last, h)
+
+
+def _pad_row_fix(d_src, d_out, g, H):
+    """Row 0 of every gathered source is read npad[a] times by atom a (a2b is right-padded with
+    bond/atom 0, features/featurization.py:286): add sum_a npad[a] * d_out[a] to d_src[0]."""
+    weighted_colsum(d_out, g.npad, H, d_src[0], accumulate=True)
+
+
+def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p: float, saved, dH, sign: float):
+    """Adjoint of mpn_forward.  `dH` is d loss / d atom_hiddens times `sign` (the reactant encoder
+    sees -d_diff, models/base_model.py:168).  Returns grads (gWi, gbi, gWh, gbh, gWo, gbo)."""
+    msgs, amsgs, a_last, h = saved
+    nA, nB = g.nA, g.nB
+    ks = 1.0 / (1.0 - p)
+    gWi, gbi = Wi.grads()
+    gWo, gbo = Wo.grads()
+    gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
+    # atom_hiddens = drop(relu([f_atoms | a_last] W_o^T + b_o))
+    wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H)
+    d_a = linear(nA, H, Wo.t(ATOM_FDIM, ATOM_FDIM + H), a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
+    # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)]
+    d_msg = gather_sum(d_a, g.b2t, H)
+    _pad_row_fix(d_msg, d_a, g, H)
+    d_inp = None
+    dz = None
+    for it in reversed(range(depth - 1)):
+        # msgs[it+1] = drop(relu(inp + m_in W_h^T + b_h)),  m_in = amsgs[it][b2a] - msgs[it][b2revb]
+        buf = torch.empty_like(d_msg) if (dz is None or dz is d_inp) else dz
+        dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
+        if d_inp is None:
+            d_inp = dz
+        wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
+              accumulate=(it != depth - 2))
+        d_min = linear(nB, H, Wh.t(0, H), a1=dz, k1=H)
+        d_a = gather_sum(d_min, g.a2b_rev_t, H)                     # sum over the atom's outgoing bonds
+        d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H, out=d_msg)
+        _pad_row_fix(d_msg, d_a, g, H)
+    # msgs[0] = relu(inp)
+    if d_inp is None:
+        d_inp = relu_bwd(d_msg, msgs[0], 1.0)
+    else:
+        buf = dz if dz is not d_inp else torch.empty_like(d_msg)
+        relu_bwd(d_msg, msgs[0], 1.0, dz=buf, acc=d_inp)
+    wgrad(nB, H, d_inp, gWi, dbias=gbi, x1=g.f_bonds, k1=FBOND)
+    return gWi, gbi, gWh, gbh, gWo, gbo
+
+
+def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Optional[LinW], p: float, seed: int,
+                    x, x_sub=None, feat=None, F: int = 0, out_drop_p: float = 0.0, out_seed: int = 0):
+    """MPNDiff.forward (models/mpn.py:170-240).  atom_features = x - x_sub (x_sub=None: x itself);
+    returns ([M, H+F] readout (+ optional FFN-input dropout), saved)."""
+    nA = g.nA
+    Hin = x.shape[1]
+    inp = _new(x, nA, H)
+    msg = _new(x, nA, H)
+    first_p = p if depth == 0 else 0.0                                                   # :221 (depth 0: dropout(message))
+    linear(nA, H, Wi.w, a1=x, k1=Hin, a1_sub=x_sub, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp,
+           drop_p=first_p, seed=_site_seed(seed, 2000))                                  # :194-195
+    msgs, amsgs = [msg], []
+    a_last = None
+    if depth > 0:
+        fb = g.fb_sum() if depth > 1 else None
+        for it in range(depth - 1):                                                      # :199
+            a_msg = gather_sum(msgs[-1], g.a2a, H)                                       # :201
+            new = linear(nA, H, Wh.w, a1=a_msg, k1=H, a2=fb, k2=FBOND, bias=Wh.b, residual=inp, act=ACT_RELU,
+                         drop_p=p, seed=_site_seed(seed, 2001 + it))                     # :202-213
+            amsgs.append(a_msg)
+            msgs.append(new)
+        a_last = gather_sum(msgs[-1], g.a2a, H)                                          # :215-216
+        hid = linear(nA, H, Wo.w, a1=x, k1=Hin, a1_sub=x_sub, a2=a_last, k2=H, bias=Wo.b, act=ACT_RELU, drop_p=p,
+                     seed=_site_seed(seed, 3000))                                        # :217-219
+    else:
+        hid = msg
+    del inp
+    vecs = segment_mean_fwd(hid, g, H, feat, F, out_drop_p, out_seed)                    # :224-238
+    return vecs, (msgs, amsgs, a_last, hid)
+
+
+def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x, x_sub, dvecs, F: int,
+                     out_drop_p: float, out_seed: int):
+    """Adjoint of mpndiff_forward -> (d_x [nA,Hin], gWi, gbi, gWh, gbh, gWo, gbo)."""
+    msgs, amsgs, a_last, hid = saved
+    nA = g.nA
+    Hin = x.shape[1]
+    ks = 1.0 / (1.0 - p)
+    gWi, gbi = Wi.grads()
+    gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
+    gWo, gbo = (Wo.grads() if Wo is not None else (None, None))
+    d_hid = segment_mean_bwd(dvecs, g, H, F, out_drop_p, out_seed)                        # [nA,H]
+    d_x = None
+    if depth > 0:
+        wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x2=a_last, k2=H)
+        # dX over both column segments of W_o: [d_x | d_a]
+        d_x = linear(nA, Hin, Wo.t(0, Hin), a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
+        d_a = linear(nA, H, Wo.t(Hin, Hin + H), a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
+        d_msg = gather_sum(d_a, g.a2a_t, H)                        # neighbour relation is symmetric
+        _pad_row_fix(d_msg, d_a, g, H)
+        d_inp, dz = None, None
+        fb = g.fb_sum() if depth > 1 else None
+        for it in reversed(range(depth - 1)):
+            buf = torch.empty_like(d_msg) if (dz is None or dz is d_inp) else dz
+            dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
+            if d_inp is None:
+                d_inp = dz
+            wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2))
+            d_a = linear(nA, H, Wh.t(0, H), a1=dz, k1=H)
+            d_msg = gather_sum(d_a, g.a2a_t, H, out=d_msg)
+            _pad_row_fix(d_msg, d_a, g, H)
+        if d_inp is None:
+            d_inp = relu_bwd(d_msg, msgs[0], 1.0)
+        else:
+            buf = dz if dz is not d_inp else torch.empty_like(d_msg)
+            relu_bwd(d_msg, msgs[0], 1.0, dz=buf, acc=d_inp)
+    else:
+        d_inp = relu_bwd(d_hid, msgs[0], ks)                        # hid = drop(relu(inp))
+    wgrad(nA, H, d_inp, gWi, dbias=gbi, x1=x, k1=Hin, x1_sub=x_sub)
+    if d_x is None:
+        d_x = linear(nA, Hin, Wi.t(0, Hin), a1=d_inp, k1=H)
+    else:
+        linear(nA, Hin, Wi.t(0, Hin), a1=d_inp, k1=H, residual=d_x, out=d_x)
+    return d_x, gWi, gbi, gWh, gbh, gWo, gbo
+
+
+def ffn_forward(x, layers: List[LinW], p: float, seed: int, head: int):
+    """FFN.forward after its first Dropout (models/base_model.py:32-60): x is already the
+    (possibly dropped) input of the first Linear.  Returns (out [M,N], saved)."""
+    M = x.shape[0]
+    hs = [x]
+    for li, L in enumerate(layers[:-1]):
+        hs.append(linear(M, L.w.shape[0], L.w, a1=hs[-1], k1=hs[-1].shape[1], bias=L.b, act=ACT_RELU, drop_p=p,
+                         seed=_site_seed(seed, 4000 + li)))
+    L = layers[-1]
+    raw = linear(M, L.w.shape[0], L.w, a1=hs[-1], k1=hs[-1].shape[1], bias=L.b)
+    out = raw if head == 0 else head_fwd(raw, head)
+    return out, (hs, raw)
+
+
+def ffn_backward(layers: List[LinW], p: float, head: int, saved, dout, need_dx: bool = True):
+    hs, raw = saved
+    M = raw.shape[0]
+    ks = 1.0 / (1.0 - p)
+    grads = []
+    d = dout if head == 0 else head_bwd(dout, raw, head)
+    L = layers[-1]
+    gw, gb = L.grads()
+    wgrad(M, L.w.shape[0], d, gw, dbias=gb, x1=hs[-1], k1=hs[-1].shape[1])
+    grads.append((gw, gb))
+    dx = None
+    if len(layers) > 1 or need_dx:
+        dx = linear(M, hs[-1].shape[1], L.t(0, hs[-1].shape[1]), a1=d, k1=L.w.shape[0])
+    for li in reversed(range(len(layers) - 1)):
+        L = layers[li]
+        gw, gb = L.grads()
+        y = hs[li + 1]                                              # drop(relu(.)) output of this layer
+        wgrad(M, L.w.shape[0], dx, gw, dbias=gb, mask=y, mask_scale=ks, x1=hs[li], k1=hs[li].shape[1])
+        grads.append((gw, gb))
+        if li > 0 or need_dx:
+            dx = linear(M, hs[li].shape[1], L.t(0, hs[li].shape[1]), a1=dx, k1=L.w.shape[0], a_mask=y, mask_scale=ks)
+    grads.reverse()
+    return dx, grads
+
+
+# =========================================================================== layer 3
+class GatherSumFn(torch.autograd.Function):
+    """index_select_ND(source, index).sum(dim=1) as one op (utils.py:176-193).  `index` follows the
+    reference convention (0 = padding row, an ordinary row here)."""
+
+    @staticmethod
+    def forward(ctx, source, index):
+        src = _rowmajor(source, "source")
+        idx = index.to(torch.int32).contiguous()
+        ctx.save_for_backward(idx)
+        ctx.n_src = src.shape[0]
+        return gather_sum(src, idx, src.shape[1])
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, = ctx.saved_tensors
+        go = _rowmajor(grad_out, "grad")
+        H = go.shape[1]
+        # transposed table built on the fly (generic index: use a sort); rows referenced many times are fine
+        flat = idx.reshape(-1).to(torch.int64)
+        order = torch.argsort(flat, stable=True)
+        rows = (order // idx.shape[1]).to(torch.int32)
+        counts = torch.bincount(flat, minlength=ctx.n_src)
+        kmax = int(counts.max().item()) if counts.numel() else 1
+        kmax = max(kmax, 1)
+        starts = torch.cumsum(counts, 0) - counts
+        tab = torch.full((ctx.n_src, kmax), -1, dtype=torch.int32, device=go.device)
+        pos = torch.arange(flat.numel(), device=go.device) - starts[flat[order]]
+        tab[flat[order], pos] = rows
+        return gather_sum(go, tab, H), None
+
+
+class ReactionModelFn(torch.autograd.Function):
+    """ReactionModel.forward (models/base_model.py:150-171) with an explicit backward."""
+
+    @staticmethod
+    def forward(ctx, st, *params):
+        # params order: enc(Wi w,b, Wh w,b, Wo w,b), diff(Wi w,b, Wh w,b, Wo w,b), ffn (w,b)*
+        enc = [LinW(params[0], params[1]), LinW(params[2], params[3]) if params[2] is not None else None,
+               LinW(params[4], params[5])]
+        dif = [LinW(params[6], params[7]), LinW(params[8], params[9]) if params[8] is not None else None,
+               LinW(params[10], params[11]) if params[10] is not None else None]
+        ffn = [LinW(params[i], params[i + 1]) for i in range(12, len(params), 2)]
+        H, p, seed = st["H"], st["p"], st["seed"]
+        rg, pg = st["r"], st["p_graph"]
+        r_h, r_saved = mpn_forward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
+        p_h, p_saved = mpn_forward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 2))
+        vecs, d_saved = mpndiff_forward(pg, H, st["diff_depth"], dif[0], dif[1], dif[2], p, _site_seed(seed, 3),
+                                        p_h, r_h, st["feat"], st["F"], out_drop_p=p, out_seed=_site_seed(seed, 4))
+        out, f_saved = ffn_forward(vecs, ffn, p, _site_seed(seed, 5), st["head"])
+        ctx.st, ctx.mods = st, (enc, dif, ffn)
+        ctx.saved = (r_saved, p_saved, d_saved, f_saved, r_h, p_h)
+        ctx.n_params = len(params)
+        ctx.present = [q is not None for q in params]
+        if st["squeeze"]:
+            out = out.reshape(-1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        st = ctx.st
+        enc, dif, ffn = ctx.mods
+        r_saved, p_saved, d_saved, f_saved, r_h, p_h = ctx.saved
+        H, p, seed = st["H"], st["p"], st["seed"]
+        rg, pg = st["r"], st["p_graph"]
+        dout = _rowmajor(dout.reshape(f_saved[1].shape), "grad_output")
+        dvecs, fg = ffn_backward(ffn, p, st["head"], f_saved, dout, need_dx=True)
+        d_diff, gWi, gbi, gWh, gbh, gWo, gbo = mpndiff_backward(pg, H, st["diff_depth"], dif[0], dif[1], dif[2], p,
+                                                                 d_saved, p_h, r_h, dvecs, st["F"], p,
+                                                                 _site_seed(seed, 4))
+        gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
+        gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_diff, -1.0)
+        genc = []
+        for a, b in zip(gp, gr):                                    # the two encoder passes share weights
+            genc.append(None if a is None else axpby(1.0, a, 1.0, b, out=a))
+        grads = list(genc) + [gWi, gbi, gWh, gbh, gWo, gbo]
+        for gw, gb in fg:
+            grads += [gw, gb]
+        grads = [gq if present else None for gq, present in zip(grads, ctx.present)]
+        ctx.saved = None
+        return (None, *grads)
+
+
+class MPNFn(torch.autograd.Function):
+    """Standalone MPN encoder (atom hiddens)."""
+
+    @staticmethod
+    def forward(ctx, st, wi, bi, wh, bh, wo, bo):
+        mods = [LinW(wi, bi), LinW(wh, bh) if wh is not None else None, LinW(wo, bo)]
+        h, saved = mpn_forward(st["g"], st["H"], st["depth"], mods[0], mods[1], mods[2], st["p"], st["seed"])
+        ctx.st, ctx.mods, ctx.saved = st, mods, saved
+        ctx.present = [q is not None for q in (wi, bi, wh, bh, wo, bo)]
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        st, m = ctx.st, ctx.mods
+        g = mpn_backward(st["g"], st["H"], st["depth"], m[0], m[1], m[2], st["p"], ctx.saved,
+                         _rowmajor(dh, "grad"), 1.0)
+        return (None, *[gq if pr else None for gq, pr in zip(g, ctx.present)])
+
+
+class MPNDiffFn(torch.autograd.Function):
+    """Standalone MPNDiff (readout vectors, no FFN-input dropout)."""
+
+    @staticmethod
+    def forward(ctx, st, x, wi, bi, wh, bh, wo, bo):
+        mods = [LinW(wi, bi), LinW(wh, bh) if wh is not None else None, LinW(wo, bo) if wo is not None else None]
+        xx = _rowmajor(x.detach(), "atom_features")
+        vecs, saved = mpndiff_forward(st["g"], st["H"], st["depth"], mods[0], mods[1], mods[2], st["p"], st["seed"],
+                                      xx, None, st["feat"], st["F"])
+        ctx.st, ctx.mods, ctx.saved, ctx.x = st, mods, saved, xx
+        ctx.present = [q is not None for q in (wi, bi, wh, bh, wo, bo)]
+        return vecs
+
+    @staticmethod
+    def backward(ctx, dvecs):
+        st, m = ctx.st, ctx.mods
+        res = mpndiff_backward(st["g"], st["H"], st["depth"], m[0], m[1], m[2], st["p"], ctx.saved, ctx.x, None,
+                               _rowmajor(dvecs, "grad"), st["F"], 0.0, 0)
+        return (None, res[0], *[gq if pr else None for gq, pr in zip(res[1:], ctx.present)])
+
+
+class FFNFn(torch.autograd.Function):
+    """Standalone FFN (first Dropout included)."""
+
+    @staticmethod
+    def forward(ctx, st, x, *params):
+        layers = [LinW(params[i], params[i + 1]) for i in range(0, len(params), 2)]
+        xx = _rowmajor(x.detach(), "ffn input")
+        p = st["p"]
+        xin = dropout(xx, p, _site_seed(st["seed"], 9)) if p > 0 else xx
+        out, saved = ffn_forward(xin, layers, p, st["seed"], st["head"])
+        ctx.st, ctx.layers, ctx.saved = st, layers, saved
+        ctx.present = [q is not None for q in params]
+        if st["squeeze"]:
+            out = out.reshape(-1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        st = ctx.st
+        dout = _rowmajor(dout.reshape(ctx.saved[1].shape), "grad_output")
+        dx, fg = ffn_backward(ctx.layers, st["p"], st["head"], ctx.saved, dout, need_dx=True)
+        if st["p"] > 0:
+            dx = dropout(dx, st["p"], _site_seed(st["seed"], 9))
+        grads = []
+        for gw, gb in fg:
+            grads += [gw, gb]
+        return (None, dx, *[gq if pr else None for gq, pr in zip(grads, ctx.present)])

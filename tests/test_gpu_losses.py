@@ -1,0 +1,144 @@
+"""GPU parity of the fused loss kernels: against vectors produced by the reference itself
+(tests/golden/losses.npz) and against the CPU oracle on fresh random lists (ragged, C in
+{1,2,3,32,64,65,129,300}).  Tolerance 1e-5 * (1 + |ref|)."""
+import numpy as np
+import pytest
+import torch
+
+from reactranker_amd import loss as RL
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+CASES = ["single", "tiny", "c32", "c64", "ragged", "long"]
+
+
+def close(got, ref, tol=1e-5, what=""):
+    got = got.detach().cpu().double().numpy().reshape(-1) if torch.is_tensor(got) else np.asarray(got, np.float64).reshape(-1)
+    ref = ref.detach().cpu().double().numpy().reshape(-1) if torch.is_tensor(ref) else np.asarray(ref, np.float64).reshape(-1)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.max(np.abs(got - ref) / (1 + np.abs(ref))) if got.size else 0
+    assert err <= tol, f"{what}: err {err:.3e}"
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_losses_against_reference_vectors(name, golden_dir):
+    L = np.load(golden_dir + "/losses.npz")
+    P = name + "."
+    scope = L[P + "scope"].tolist()
+    targets = torch.tensor(L[P + "targets"])
+
+    def fresh():
+        return torch.tensor(L[P + "score"]).cuda().requires_grad_(True)
+
+    s = fresh()
+    l = RL.MLEloss()(s, scope, targets, 0)
+    assert l.shape == (1,)
+    l.sum().backward()
+    close(l, L[P + "mle"], what="mle"); close(s.grad, L[P + "mle_g"], what="mle_g")
+
+    s = fresh()
+    l = RL.ListnetLoss()(s, scope, targets, 0)
+    assert l.dim() == 0
+    l.backward()
+    close(l, L[P + "listnet"], what="listnet"); close(s.grad, L[P + "listnet_g"], what="listnet_g")
+
+    poss = torch.stack([torch.tensor(L[P + "score"]), torch.tensor(L[P + "var"])], 1).cuda().requires_grad_(True)
+    l = RL.evidential_ranking()(poss, scope, targets, 0.01, 0, 10, 0)
+    assert l.shape == (1,)
+    l.sum().backward()
+    close(l, L[P + "evid"], what="evid")
+    close(poss.grad[:, 0], L[P + "evid_gs"], tol=2e-5, what="evid_gs")
+    close(poss.grad[:, 1], L[P + "evid_gv"], tol=2e-5, what="evid_gv")
+
+    s = fresh()
+    l = RL.MSELoss()(s, targets)
+    l.backward()
+    close(l, L[P + "mse"]); close(s.grad, L[P + "mse_g"])
+
+    s = fresh()
+    v = torch.tensor(L[P + "var"]).cuda().requires_grad_(True)
+    l = RL.GaussDisLoss()(s, v, targets, 0)
+    l.backward()
+    close(l, L[P + "gauss"]); close(s.grad, L[P + "gauss_gs"]); close(v.grad, L[P + "gauss_gv"], tol=2e-5)
+
+    for sigma in (1.0, 0.5):
+        s = fresh()
+        ls, pairs = RL.ranknet_loss(s, scope, targets, sigma, 0)
+        assert int(pairs.item()) == int(L[P + "rank_pairs"])
+        if int(pairs.item()) == 0:
+            assert float(ls) == 0.0
+            continue
+        (ls / pairs).backward()
+        close(ls / pairs, L[P + f"rank_ss_{sigma}"], what="rank_ss")
+        close(s.grad, L[P + f"rank_ss_g_{sigma}"], what="rank_ss_g")
+        lam = RL.ranknet_lambda(s.detach(), scope, targets, sigma, 0) / pairs
+        close(lam, L[P + f"rank_ag_g_{sigma}"], what="rank_ag_g")
+
+
+def test_logcumsumexp_op_and_ranknet_overflow(golden_dir):
+    L = np.load(golden_dir + "/losses.npz")
+    for nm in ("lce_small", "lce_large"):
+        x = torch.tensor(L[nm + ".x"]).cuda().requires_grad_(True)
+        y = RL.LogCumsumExp.apply(x)
+        y.backward(torch.tensor(L[nm + ".go"]).cuda())
+        close(y, L[nm + ".y"], what=nm)
+        ref = L[nm + ".g"]
+        sc = max(1.0, float(np.abs(ref).max()))
+        close(x.grad / sc, ref / sc, what=nm + ".g")
+    ls, pairs = RL.ranknet_loss(torch.tensor(L["rank_overflow.score"]).cuda(), [3],
+                                torch.tensor(L["rank_overflow.targets"]), 1.0, 0)
+    assert torch.isinf(ls) and int(pairs) == 6          # naive log(1+exp(x)) overflows like the reference (H4)
+
+
+@pytest.mark.parametrize("seed,scope", [(0, [1, 2, 3, 32, 64, 65, 129, 300]), (1, [64] * 64), (2, [5, 1, 1, 7]),
+                                        (3, [1000])])
+def test_losses_against_oracle_random(seed, scope):
+    rng = np.random.default_rng(seed)
+    m = sum(scope)
+    score = (rng.standard_normal(m) * 2).astype(np.float32)
+    targets = np.concatenate([rng.permutation(c) for c in scope]).astype(np.float32)
+    targets = ((targets - targets.mean()) / (targets.std() + 1e-6)).astype(np.float32)
+    var = (np.log1p(np.exp(rng.standard_normal(m))) + 1e-6).astype(np.float32)
+    ts, tt, tv = torch.tensor(score, requires_grad=True), torch.tensor(targets), torch.tensor(var, requires_grad=True)
+
+    ref = O.listmle_loss(ts, scope, tt); g_ref, = torch.autograd.grad(ref.sum(), ts)
+    s = torch.tensor(score).cuda().requires_grad_(True)
+    l = RL.MLEloss()(s, scope, tt, 0); l.sum().backward()
+    close(l, ref, what="mle"); close(s.grad, g_ref, what="mle_g")
+
+    ref = O.listnet_loss(ts, scope, tt); g_ref, = torch.autograd.grad(ref, ts)
+    s = torch.tensor(score).cuda().requires_grad_(True)
+    l = RL.ListnetLoss()(s, scope, tt, 0); l.backward()
+    close(l, ref, what="listnet"); close(s.grad, g_ref, what="listnet_g")
+
+    ref = O.evidential_ranking_loss(torch.stack([ts, tv], 1), scope, tt)
+    gs_ref, gv_ref = torch.autograd.grad(ref.sum(), [ts, tv])
+    poss = torch.stack([torch.tensor(score), torch.tensor(var)], 1).cuda().requires_grad_(True)
+    l = RL.evidential_ranking()(poss, scope, tt, None, None, None, 0); l.sum().backward()
+    close(l, ref, tol=2e-5, what="evid")
+    sc = max(1.0, float(gv_ref.abs().max()))
+    close(poss.grad[:, 0], gs_ref, tol=5e-5, what="evid_gs"); close(poss.grad[:, 1] / sc, gv_ref / sc, tol=5e-5, what="evid_gv")
+
+    ref, pairs_ref = O.ranknet_sum_session(ts, scope, tt, 1.0)
+    s = torch.tensor(score).cuda().requires_grad_(True)
+    ls, pairs = RL.ranknet_loss(s, scope, tt, 1.0, 0)
+    assert int(pairs) == int(pairs_ref)
+    if pairs_ref > 0:
+        g_ref, = torch.autograd.grad(ref / pairs_ref, ts)
+        (ls / pairs).backward()
+        close(ls / pairs, ref / pairs_ref, what="ranknet"); close(s.grad, g_ref, what="ranknet_g")
+
+
+def test_strided_score_column_and_query_permutation_invariance():
+    rng = np.random.default_rng(9)
+    scope = [64] * 16
+    m = sum(scope)
+    out = torch.tensor(rng.standard_normal((m, 2)).astype(np.float32)).cuda()
+    targets = torch.tensor(np.concatenate([rng.permutation(64) for _ in scope]).astype(np.float32) / 64)
+    a = RL.MLEloss()(out[:, 0], scope, targets, 0)
+    b = RL.MLEloss()(out[:, 0].contiguous(), scope, targets, 0)
+    assert torch.equal(a, b)
+    perm = rng.permutation(16)
+    idx = np.concatenate([np.arange(q * 64, (q + 1) * 64) for q in perm])
+    c = RL.MLEloss()(out[:, 0].contiguous()[idx], scope, targets[idx], 0)
+    close(c, a, tol=1e-6, what="query order")

@@ -1,0 +1,305 @@
+"""GPU parity of the whole path behind the reference's own call signatures:
+build_model(...) -> model(r_batch, p_batch, gpu, add_features) -> loss(score, scope, targets, gpu),
+against (i) vectors produced by the reference itself (tests/golden/model_*.npz) and (ii) the CPU
+oracle, including train-mode dropout with the same counter-based masks.
+Tolerances: scores / loss 1e-5 * (1 + |ref|) (north star); gradients 5e-5 of the tensor's max-abs;
+candidate ordering and NDCG@10 identical."""
+import numpy as np
+import pytest
+import torch
+
+from reactranker_amd import featurization, synth
+from reactranker_amd import loss as RL
+from reactranker_amd.base_model import build_model
+from reactranker_amd.utils import index_select_ND, index_select_sum, load_checkpoint, save_checkpoint
+from oracle import dropout_ref as DR
+from oracle import ref_cpu as O
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, ref, tol=1e-5, what=""):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.max(np.abs(got - ref) / (1 + np.abs(ref))) if got.size else 0.0
+    assert err <= tol, f"{what}: err {err:.3e} > {tol}"
+    return err
+
+
+def make_model(cfg, w, dropout=0.0):
+    kw = {k: cfg[k] for k in ("hidden_size", "mpnn_depth", "mpnn_diff_depth", "ffn_depth", "use_bias", "task_num",
+                              "ffn_last_layer", "task_type", "add_features_dim")}
+    model = build_model(dropout=dropout, **kw)
+    missing = model.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.cuda()
+
+
+def check_grads(model, d, prefix, H, tol=5e-5):
+    seen = 0
+    for k, p in model.named_parameters():
+        key = prefix + "." + k
+        if key not in d.files:
+            continue
+        seen += 1
+        ref = d[key]
+        g = torch.zeros_like(p) if p.grad is None else p.grad
+        got = Hh.sample_like(g.detach().cpu().numpy(), H)
+        s = max(1e-3, float(np.abs(ref).max()))
+        close(got / s, ref / s, tol=tol, what=key)
+    assert seen > 0, prefix
+
+
+@pytest.mark.parametrize("path", Hh.model_case_files(), ids=lambda p: p.split("model_")[-1][:-4])
+def test_model_against_reference_vectors(path):
+    d, cfg = Hh.load_case(path)
+    H = cfg["hidden_size"]
+    shapes = O.model_shapes(H, cfg["mpnn_depth"], cfg["mpnn_diff_depth"], cfg["ffn_depth"], cfg["task_num"],
+                            cfg["add_features_dim"], cfg["use_bias"])
+    w = Hh.case_weights(d, cfg, shapes)
+    model = make_model(cfg, w).eval()
+    assert model.ffn.task_type == cfg["head"]
+    qb = Hh.case_queries(cfg)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs), featurization.BatchMolGraph(qb.p_specs)
+    add = d["add_features"] if "add_features" in d.files else None
+    targets = torch.tensor(d["targets"])
+    scope = cfg["scope"]
+
+    # encoder / diff-encoder modules on their own (same call shapes as the reference)
+    n = d["r_h"].shape[0]
+    r_h = model.encoder(rb, 0)
+    p_h = model.encoder(pb, 0)
+    close(r_h[:n], d["r_h"], what="r_h")
+    close(p_h[:n], d["p_h"], what="p_h")
+    vecs = model.diff_encoder(p_h - r_h, pb, 0, features_batch=add)
+    close(vecs, d["vecs"], what="vecs")
+    close(model.ffn(vecs), d["out"], what="ffn(vecs)")
+    msg = torch.relu(model.encoder.W_i(rb.f_bonds.cuda()))
+    gs = index_select_ND(msg, rb.a2b.cuda()).sum(dim=1)
+    close(gs[:64], d["gather_sum_r"], what="index_select_ND")
+    close(index_select_sum(msg, rb.a2b.cuda())[:64], d["gather_sum_r"], what="index_select_sum")
+
+    out = model(rb, pb, gpu=0, add_features=add)
+    assert tuple(out.shape) == tuple(d["out"].shape)
+    close(out, d["out"], what="out")
+
+    def run(loss_fn, lname, gprefix):
+        model.zero_grad()
+        o = model(rb, pb, gpu=0, add_features=add)
+        l = loss_fn(o)
+        close(l.reshape(-1), np.asarray(d[lname]).reshape(-1), what=lname)
+        l.sum().backward()
+        if (gprefix + ".encoder.W_i.weight") in d.files:
+            check_grads(model, d, gprefix, H)
+
+    if "loss_mle" in d.files:
+        run(lambda o: RL.MLEloss()(o if o.dim() == 1 else o[:, 0], scope, targets, 0), "loss_mle", "gmle")
+    if "loss_listnet" in d.files:
+        run(lambda o: RL.ListnetLoss()(o, scope, targets, 0), "loss_listnet", "glistnet")
+    if "loss_mse" in d.files:
+        run(lambda o: RL.MSELoss()(o, targets), "loss_mse", "gmse")
+    if "loss_evidential" in d.files:
+        run(lambda o: RL.evidential_ranking()(o, scope, targets, 0.01, 0, 10, 0), "loss_evidential", "gevidential")
+    if "loss_gauss" in d.files:
+        def gl(o):
+            var = o[:, 1] if "with_softplus" in cfg["head"] else torch.exp(o[:, 1])
+            return RL.GaussDisLoss()(o[:, 0], var, targets, 0)
+        run(gl, "loss_gauss", "ggauss")
+    if "loss_lin" in d.files:
+        lin = torch.linspace(0.5, 1.5, int(np.prod(d["out"].shape))).cuda()
+        run(lambda o: (o * lin.view_as(o)).sum(), "loss_lin", "glin")
+
+    # candidate ordering (eval.py:516-519) and NDCG@10 (metrics.py) identical to the reference's
+    sc = out.detach().cpu()
+    sc1 = (sc[:, 0] if sc.dim() > 1 else sc).numpy()
+    ref1 = d["out"][:, 0] if d["out"].ndim > 1 else d["out"]
+    order, nd, off, min_gap = [], [], 0, np.inf
+    for cnt in scope:
+        o = O.ranking_order(sc1[off:off + cnt].tolist())
+        order.extend(o)
+        srt = np.sort(ref1[off:off + cnt])
+        if cnt > 1:
+            min_gap = min(min_gap, float(np.min(np.diff(srt))))
+        ts = d["targets"][off:off + cnt]
+        rel = np.argsort(np.argsort(ts)).astype(np.float64) / max(1, cnt - 1) * 4.0
+        nd.append(O.ndcg(rel[o], 10))
+        off += cnt
+    err = float(np.max(np.abs(sc1 - ref1)))
+    if min_gap > 2 * err:                                # ordering is only meaningful above the achieved error (H3)
+        assert np.array_equal(np.asarray(order, np.int32), d["order"])
+        assert np.allclose(nd, d["ndcg10"], rtol=0, atol=1e-12)
+
+
+def _masks_for(model, seed, rg, pg, M, F, p):
+    """The keep-masks the HIP epilogues generate for dropout stream `seed`, keyed like oracle/ref_cpu."""
+    H = model.encoder.hidden_size
+    ss = DR.site_seed
+
+    def mk(s, rows, cols):
+        return torch.from_numpy(DR.keep_mask(s, np.arange(rows * cols, dtype=np.uint64), p).reshape(rows, cols)).float()
+    masks = {}
+    for tag, site, g in (("r", 1, rg), ("p", 2, pg)):
+        s_enc = ss(seed, site)
+        for it in range(model.encoder.depth - 1):
+            masks[f"{tag}.enc.{it}"] = mk(ss(s_enc, it), g.n_bonds, H)
+        masks[f"{tag}.enc.out"] = mk(ss(s_enc, 1000), g.n_atoms, H)
+    s_d = ss(seed, 3)
+    dd = model.diff_encoder.depth
+    for it in range(dd - 1):
+        masks[f"diff.{it}"] = mk(ss(s_d, 2001 + it), pg.n_atoms, H)
+    masks["diff.out"] = mk(ss(s_d, 3000 if dd > 0 else 2000), pg.n_atoms, H)
+    masks["ffn.0"] = mk(ss(seed, 4), M, H + F)
+    s_f = ss(seed, 5)
+    lins = model.ffn.linears()
+    for li, lin in enumerate(lins[:-1]):
+        masks[f"ffn.{li + 1}"] = mk(ss(s_f, 4000 + li), M, lin.out_features)
+    return masks
+
+
+@pytest.mark.parametrize("cfgname,p", [("A_h32_d3_mle", 0.25), ("C_h32_d2_evidential_ranking", 0.1),
+                                       ("G_h32_dd0_listnet_softplus", 0.3), ("F_h300_d3_c64", 0.1)])
+def test_train_mode_dropout_matches_oracle_with_same_masks(cfgname, p, golden_dir):
+    d, cfg = Hh.load_case(f"{golden_dir}/model_{cfgname}.npz")
+    H = cfg["hidden_size"]
+    shapes = O.model_shapes(H, cfg["mpnn_depth"], cfg["mpnn_diff_depth"], cfg["ffn_depth"], cfg["task_num"],
+                            cfg["add_features_dim"], cfg["use_bias"])
+    w = Hh.case_weights(d, cfg, shapes)
+    model = make_model(cfg, w, dropout=p).train()
+    model.dropout_seed = 0xC0FFEE1234
+    qb = Hh.case_queries(cfg)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs), featurization.BatchMolGraph(qb.p_specs)
+    add = d["add_features"] if "add_features" in d.files else None
+    F = 0 if add is None else add.shape[1]
+    scope, targets = cfg["scope"], torch.tensor(d["targets"])
+    masks = _masks_for(model, model.dropout_seed, rb, pb, len(qb.p_specs), F, p)
+
+    P = O.params_from_numpy(w, requires_grad=True)
+    mc = dict(depth=cfg["mpnn_depth"], diff_depth=cfg["mpnn_diff_depth"], ffn_depth=cfg["ffn_depth"],
+              task_type=cfg["head"], dropout=p)
+    ref = O.reaction_forward(P, mc, Hh.golden_graph(d, "r_"), Hh.golden_graph(d, "p_"), add, masks=masks)
+    out = model(rb, pb, gpu=0, add_features=add)
+    close(out, ref, tol=2e-5, what="train-mode out")
+    assert float((out.detach().cpu() - torch.tensor(d["out"])).abs().max()) > 1e-4      # dropout really acted
+    if cfg["task_num"] == 1:
+        l_ref = O.listmle_loss(ref, scope, targets)
+        l = RL.MLEloss()(out, scope, targets, 0)
+    else:
+        l_ref = O.evidential_ranking_loss(ref, scope, targets)
+        l = RL.evidential_ranking()(out, scope, targets, None, None, None, 0)
+    close(l, l_ref, tol=2e-5, what="train-mode loss")
+    names = [k for k in P if P[k].requires_grad]
+    g_ref = torch.autograd.grad(l_ref.sum(), [P[k] for k in names], allow_unused=True)
+    l.sum().backward()
+    got = dict(model.named_parameters())
+    for k, gr in zip(names, g_ref):
+        gr = torch.zeros_like(P[k]) if gr is None else gr
+        g = got[k].grad
+        g = torch.zeros_like(got[k]) if g is None else g
+        s = max(1e-3, float(gr.abs().max()))
+        close(g / s, gr / s, tol=1e-4, what="train grad " + k)
+
+
+def test_reference_style_batch_objects_and_checkpoint_roundtrip(tmp_path, golden_dir):
+    """A batch object that only offers the reference's get_components()/get_a2a() contract
+    (LongTensors, python a_scope) drives the model, and checkpoints keep the reference layout."""
+    d, cfg = Hh.load_case(f"{golden_dir}/model_A_h32_d3_mle.npz")
+    shapes = O.model_shapes(32, 3, 3, 3, 1, 1, True)
+    model = make_model(cfg, Hh.case_weights(d, cfg, shapes)).eval()
+
+    class RefLikeBatch:
+        def __init__(self, pre):
+            self.c = (torch.tensor(d[pre + "f_atoms"]), torch.tensor(d[pre + "f_bonds"]),
+                      torch.tensor(d[pre + "a2b"]).long(), torch.tensor(d[pre + "b2a"]).long(),
+                      torch.tensor(d[pre + "b2revb"]).long(), [tuple(r) for r in d[pre + "a_scope"].tolist()],
+                      [tuple(r) for r in d[pre + "b_scope"].tolist()])
+            self.a2a = None
+
+        def get_components(self):
+            return self.c
+
+        def get_a2a(self):
+            return self.c[3][self.c[2]]
+    out = model(RefLikeBatch("r_"), RefLikeBatch("p_"), gpu=0, add_features=d["add_features"])
+    close(out, d["out"], what="ref-like batch")
+    path = str(tmp_path / "ck" / "model.pt")
+    save_checkpoint(path, model, means=1.5, stds=0.5)
+    st = torch.load(path, weights_only=False)
+    assert set(st) == {"state_dict", "data_scaler"} and st["data_scaler"] == {"means": 1.5, "stds": 0.5}
+    m2 = build_model(dropout=0.0, **{k: cfg[k] for k in ("hidden_size", "mpnn_depth", "mpnn_diff_depth", "ffn_depth",
+                                                         "use_bias", "task_num", "ffn_last_layer", "task_type",
+                                                         "add_features_dim")}).cuda().eval()
+    assert load_checkpoint(path, m2) == {"means": 1.5, "stds": 0.5}
+    qb = Hh.case_queries(cfg)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs), featurization.BatchMolGraph(qb.p_specs)
+    assert torch.equal(m2(rb, pb, 0, d["add_features"]), model(rb, pb, 0, d["add_features"]))
+
+
+def test_global_pad_width_changes_scores_like_the_reference():
+    """Hazard H1: scores depend on the batch's pad width K; a wider global K must still match the
+    oracle run with that K (this is what keeps 1-GPU and N-GPU results identical)."""
+    cfg = dict(hidden_size=32, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
+               ffn_last_layer="no_softplus", task_type=None, add_features_dim=1)
+    shapes = O.model_shapes(32, 3, 3, 3, 1, 1, True)
+    w = synth.seeded_weights(shapes, 5)
+    model = make_model(cfg, w).eval()
+    qb = synth.make_queries(21, 3, [4, 5, 3], atoms_lo=5, atoms_hi=9)
+    outs = {}
+    for K in (None, 6):
+        rb, pb = featurization.BatchMolGraph(qb.r_specs, K=K), featurization.BatchMolGraph(qb.p_specs, K=K)
+        out = model(rb, pb, 0, qb.add_features)
+        ref = O.reaction_forward(O.params_from_numpy(w), dict(depth=3, diff_depth=3, ffn_depth=3, task_type="no_softplus"),
+                                 O.pack_batch(qb.r_specs, K=K), O.pack_batch(qb.p_specs, K=K), qb.add_features)
+        close(out, ref, what=f"K={K}")
+        outs[K] = out
+    assert float((outs[None] - outs[6]).abs().max()) > 1e-4
+
+
+def test_full_step_size_properties():
+    """BASELINE config-3 step (64 queries x 64 candidates, H=300, d=3): size-independent properties —
+    run-to-run determinism, query-order invariance of scores, shard-sum == whole-batch gradient
+    (the data-parallel identity of SURVEY.md section 8e) — plus a spot check against the oracle."""
+    cfg = dict(hidden_size=300, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
+               ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
+    shapes = O.model_shapes(300, 3, 3, 3, 1, 1, True)
+    w = synth.seeded_weights(shapes, 77)
+    model = make_model(cfg, w).eval()
+    Q, Cn = 64, 64
+    qb = synth.make_queries(123, Q, Cn)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    scope, targets = qb.scope, torch.tensor(qb.targets)
+    out1 = model(rb, pb, 0, qb.add_features)
+    l1 = RL.MLEloss()(out1, scope, targets, 0)
+    model.zero_grad(); l1.sum().backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    out2 = model(rb, pb, 0, qb.add_features)
+    l2 = RL.MLEloss()(out2, scope, targets, 0)
+    model.zero_grad(); l2.sum().backward()
+    assert torch.equal(out1, out2) and torch.equal(l1, l2)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g1[k]), k                      # no float atomics anywhere
+    # two shards of 32 queries: mean of shard losses == loss, mean of shard grads == grads
+    acc = {k: torch.zeros_like(v) for k, v in g1.items()}
+    lsum = 0.0
+    for lo in (0, 32):
+        sl = slice(lo * Cn, (lo + 32) * Cn)
+        rs, ps = featurization.BatchMolGraph(qb.r_specs[sl], K=4), featurization.BatchMolGraph(qb.p_specs[sl], K=4)
+        o = model(rs, ps, 0, qb.add_features[sl])
+        close(o, out1[sl], tol=1e-6, what="shard scores")
+        l = RL.MLEloss()(o, scope[lo:lo + 32], targets[sl], 0)
+        model.zero_grad(); l.sum().backward()
+        lsum += float(l)
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                acc[k] += p.grad * 0.5
+    assert abs(lsum / 2 - float(l1)) < 1e-5 * (1 + abs(float(l1)))
+    for k in g1:
+        s = max(1e-3, float(g1[k].abs().max()))
+        close(acc[k] / s, g1[k] / s, tol=5e-5, what="shard grads " + k)
+    # oracle spot check on the first 4 queries
+    sl = slice(0, 4 * Cn)
+    ref = O.reaction_forward(O.params_from_numpy(w), dict(depth=3, diff_depth=3, ffn_depth=3, task_type="with_softplus"),
+                             O.pack_batch(qb.r_specs[sl], K=4), O.pack_batch(qb.p_specs[sl], K=4), qb.add_features[sl])
+    close(out1[sl], ref, what="oracle spot check")

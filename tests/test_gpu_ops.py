@@ -1,0 +1,233 @@
+"""GPU parity of the individual HIP ops (called through the C-ABI) against plain fp32 math on the
+CPU.  Tolerance for floating point: |got - ref| <= 1e-5 * (1 + |ref|) (north star: 1e-5 fp32);
+index / mask results are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from reactranker_amd import functions as Fn
+from reactranker_amd import _lib
+from oracle import dropout_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def dev(a):
+    return torch.as_tensor(a).cuda()
+
+
+def close(got, ref, tol=TOL, what=""):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    if got.size == 0:
+        return
+    err = np.max(np.abs(got - ref) / (1 + np.abs(ref)))
+    assert err <= tol, f"{what}: err {err:.3e} > {tol}"
+
+
+@pytest.mark.parametrize("H,ld", [(300, 300), (32, 32), (30, 30), (83, 84), (600, 600)])
+def test_gather_sum_and_diff(H, ld):
+    rng = np.random.default_rng(H)
+    n_src, n_out, K = 517, 301, 4
+    src = np.zeros((n_src, ld), np.float32)
+    src[:, :H] = rng.standard_normal((n_src, H))
+    idx = rng.integers(-1, n_src, size=(n_out, K)).astype(np.int32)
+    idx[0] = 0
+    ref = np.where(idx[..., None] >= 0, src[np.maximum(idx, 0)][..., :H], 0).astype(np.float32).sum(1)
+    got = Fn.gather_sum(dev(src), dev(idx), H)
+    close(got, ref, what="gather_sum")
+    ia = rng.integers(-1, n_src, size=n_out).astype(np.int32)
+    im = rng.integers(-1, n_src, size=n_out).astype(np.int32)
+    ref = np.where(ia[:, None] >= 0, src[np.maximum(ia, 0)][:, :H], 0) - np.where(im[:, None] >= 0, src[np.maximum(im, 0)][:, :H], 0)
+    got = Fn.gather_diff(dev(src), dev(ia), dev(src), dev(im), H)
+    assert np.array_equal(got.cpu().numpy(), ref.astype(np.float32))          # one subtraction: bit-exact
+    # K = 1, 1-D index (the backward use)
+    got = Fn.gather_sum(dev(src), dev(ia), H)
+    assert np.array_equal(got.cpu().numpy(), np.where(ia[:, None] >= 0, src[np.maximum(ia, 0)][:, :H], 0).astype(np.float32))
+
+
+def test_gather_sum_is_deterministic_and_linear():
+    rng = np.random.default_rng(1)
+    src = dev(rng.standard_normal((70000, 300)).astype(np.float32))
+    idx = dev(rng.integers(0, 70000, size=(40000, 4)).astype(np.int32))
+    a = Fn.gather_sum(src, idx, 300)
+    b = Fn.gather_sum(src, idx, 300)
+    assert torch.equal(a, b)
+    close(Fn.gather_sum(src * 2, idx, 300), a * 2, what="linearity")
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 1000, 70001])
+def test_weighted_colsum(n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 300)).astype(np.float32)
+    w = rng.integers(0, 5, size=n).astype(np.float32)
+    out = torch.full((300,), 2.0, device="cuda")
+    Fn.weighted_colsum(dev(x), dev(w), 300, out, accumulate=True)
+    ref = 2.0 + (w[:, None].astype(np.float64) * x).sum(0)
+    close(out, ref, tol=2e-5, what="colsum")
+    out2 = torch.empty(300, device="cuda")
+    Fn.weighted_colsum(dev(x), None, 300, out2, accumulate=False)
+    close(out2, x.astype(np.float64).sum(0), tol=2e-5)
+
+
+def _ref_linear(a, w, bias, res, act):
+    y = a.double() @ w.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if res is not None:
+        y = y + res.double()
+    pre = y.clone()
+    if act:
+        y = torch.relu(y)
+    return y, pre
+
+
+@pytest.mark.parametrize("M", [1, 63, 64, 65, 1000])
+@pytest.mark.parametrize("N,K,ldk", [(300, 300, 300), (300, 83, 84), (32, 32, 32), (1, 300, 300), (2, 32, 32),
+                                     (100, 301, 301), (600, 600, 600), (301, 64, 64), (160, 48, 48)])
+def test_linear_plain(M, N, K, ldk):
+    torch.manual_seed(M * 1000 + N + K)
+    a = torch.zeros(M, ldk)
+    a[:, :K] = torch.randn(M, K)
+    w = torch.randn(N, K) / K ** 0.5
+    bias = torch.randn(N)
+    res = torch.randn(M, N)
+    ref, pre = _ref_linear(a[:, :K], w, bias, res, True)
+    pre_out = torch.empty(M, N, device="cuda")
+    got = Fn.linear(M, N, w.cuda(), a1=a.cuda(), k1=K, bias=bias.cuda(), residual=res.cuda(), act=Fn.ACT_RELU,
+                    c_pre=pre_out)
+    close(got, ref, what="linear relu")
+    close(pre_out, pre, what="linear pre")
+    got = Fn.linear(M, N, w.cuda(), a1=a.cuda(), k1=K)
+    close(got, a[:, :K].double() @ w.double().t(), what="linear bare")
+
+
+@pytest.mark.parametrize("H", [300, 32, 30])
+def test_linear_concat_gather_mask(H):
+    torch.manual_seed(H)
+    nA, nB = 211, 397
+    f_atoms = torch.zeros(nA, 64); f_atoms[:, :61] = torch.rand(nA, 61)
+    a_msg = torch.randn(nA, H)
+    w = torch.randn(H, 61 + H) / 10
+    b = torch.randn(H)
+    ref = torch.relu(torch.cat([f_atoms[:, :61], a_msg], 1).double() @ w.double().t() + b.double())
+    got = Fn.linear(nA, H, w.cuda(), a1=f_atoms.cuda(), k1=61, a2=a_msg.cuda(), k2=H, bias=b.cuda(), act=Fn.ACT_RELU)
+    close(got, ref, what="concat")
+    # gather + subtract prologue
+    msg = torch.randn(nB, H)
+    b2a = torch.randint(0, nA, (nB,), dtype=torch.int32)
+    b2r = torch.randint(0, nB, (nB,), dtype=torch.int32)
+    wh = torch.randn(H, H) / H ** 0.5
+    inp = torch.randn(nB, H)
+    m_in = a_msg[b2a.long()] - msg[b2r.long()]
+    ref = torch.relu(inp.double() + m_in.double() @ wh.double().t())
+    got = Fn.linear(nB, H, wh.cuda(), a1=a_msg.cuda(), k1=H, a1_idx=b2a.cuda(), a1_sub=msg.cuda(),
+                    a1_sub_idx=b2r.cuda(), residual=inp.cuda(), act=Fn.ACT_RELU)
+    close(got, ref, what="gather-sub")
+    # plain subtract (diff = p - r) with a second segment
+    p_h, r_h = torch.randn(nA, H), torch.randn(nA, H)
+    w2 = torch.randn(H, 2 * H) / H ** 0.5
+    ref = torch.cat([p_h - r_h, a_msg], 1).double() @ w2.double().t()
+    got = Fn.linear(nA, H, w2.cuda(), a1=p_h.cuda(), k1=H, a1_sub=r_h.cuda(), a2=a_msg.cuda(), k2=H)
+    close(got, ref, what="sub+concat")
+    # relu-backward mask prologue
+    dy, y = torch.randn(nB, H), torch.relu(torch.randn(nB, H))
+    ref = (dy * (y > 0) * 1.25).double() @ wh.double().t()
+    got = Fn.linear(nB, H, wh.cuda(), a1=dy.cuda(), k1=H, a_mask=y.cuda(), mask_scale=1.25)
+    close(got, ref, what="mask")
+    # in-place residual accumulate
+    c = torch.randn(nB, H)
+    cc = c.cuda()
+    Fn.linear(nB, H, wh.cuda(), a1=dy.cuda(), k1=H, residual=cc, out=cc)
+    close(cc, c.double() + dy.double() @ wh.double().t(), what="inplace")
+
+
+def test_linear_dropout_matches_stream():
+    torch.manual_seed(0)
+    M, N, K, p, seed = 130, 300, 64, 0.2, 0x1234567890ABCDEF
+    a, w = torch.randn(M, K), torch.randn(N, K) / 8
+    ref = torch.relu(a.double() @ w.double().t())
+    keep = dropout_ref.keep_mask(seed, np.arange(M * N, dtype=np.uint64), p).reshape(M, N)
+    ref = torch.where(torch.from_numpy(keep), ref / (1 - np.float32(p)).astype(np.float64), torch.zeros_like(ref))
+    got = Fn.linear(M, N, w.cuda(), a1=a.cuda(), k1=K, act=Fn.ACT_RELU, drop_p=p, seed=seed)
+    close(got, ref, what="dropout epilogue")
+    x = torch.randn(1000)
+    got = Fn.dropout(x.cuda(), p, seed)
+    keep = dropout_ref.keep_mask(seed, np.arange(1000, dtype=np.uint64), p)
+    assert np.array_equal((got.cpu().numpy() != 0), keep & (x.numpy() != 0))
+
+
+@pytest.mark.parametrize("M", [1, 16, 100, 5000, 70000])
+@pytest.mark.parametrize("N,k1,k2", [(300, 300, 0), (300, 83, 0), (300, 61, 300), (32, 32, 83), (1, 300, 0), (2, 33, 0),
+                                     (300, 300, 83)])
+def test_wgrad(M, N, k1, k2):
+    if M == 70000 and N < 300:
+        pytest.skip("large-M only for the hot shapes")
+    torch.manual_seed(M + N + k1 + k2)
+    ld1 = (k1 + 3) // 4 * 4
+    x1 = torch.zeros(M, ld1); x1[:, :k1] = torch.randn(M, k1)
+    x2 = torch.randn(M, k2) if k2 else None
+    dy = torch.randn(M, N)
+    y = torch.relu(torch.randn(M, N))
+    dz = (dy * (y > 0) * 0.5).double()
+    X = x1[:, :k1].double() if x2 is None else torch.cat([x1[:, :k1], x2], 1).double()
+    ref_w, ref_b = dz.t() @ X, dz.sum(0)
+    dw = torch.empty(N, k1 + k2, device="cuda"); db = torch.empty(N, device="cuda")
+    Fn.wgrad(M, N, dy.cuda(), dw, dbias=db, mask=y.cuda(), mask_scale=0.5, x1=x1.cuda(), k1=k1,
+             x2=None if x2 is None else x2.cuda(), k2=k2)
+    s = max(1.0, float(ref_w.abs().max()))
+    close(dw / s, ref_w / s, tol=2e-5, what="dw")
+    close(db / s, ref_b / s, tol=2e-5, what="db")
+    Fn.wgrad(M, N, dy.cuda(), dw, dbias=db, mask=y.cuda(), mask_scale=0.5, x1=x1.cuda(), k1=k1,
+             x2=None if x2 is None else x2.cuda(), k2=k2, accumulate=True)
+    close(dw / s, 2 * ref_w / s, tol=4e-5, what="dw accumulate")
+
+
+def test_wgrad_gather_sub_operand():
+    torch.manual_seed(3)
+    nA, nB, H = 150, 290, 300
+    a_msg, msg, dz = torch.randn(nA, H), torch.randn(nB, H), torch.randn(nB, H)
+    b2a = torch.randint(0, nA, (nB,), dtype=torch.int32)
+    b2r = torch.randint(0, nB, (nB,), dtype=torch.int32)
+    X = (a_msg[b2a.long()] - msg[b2r.long()]).double()
+    dw = torch.empty(H, H, device="cuda")
+    Fn.wgrad(nB, H, dz.cuda(), dw, x1=a_msg.cuda(), k1=H, x1_idx=b2a.cuda(), x1_sub=msg.cuda(), x1_sub_idx=b2r.cuda())
+    ref = dz.double().t() @ X
+    s = float(ref.abs().max())
+    close(dw / s, ref / s, tol=2e-5, what="dw gather-sub")
+
+
+def test_relu_bwd_axpby_head_segment():
+    torch.manual_seed(5)
+    dy, y, acc = torch.randn(1001, 30), torch.relu(torch.randn(1001, 30)), torch.randn(1001, 30)
+    a = acc.cuda()
+    dz = Fn.relu_bwd(dy.cuda(), y.cuda(), -1.5, acc=a)
+    ref = dy * (y > 0) * -1.5
+    assert torch.equal(dz.cpu(), ref)
+    close(a, acc + ref)
+    close(Fn.axpby(2.0, dy.cuda(), -1.0, y.cuda()), 2 * dy - y)
+    for head, N in ((0, 1), (1, 1), (2, 1), (3, 2), (4, 2), (5, 2), (6, 4), (3, 4), (6, 8)):
+        raw = torch.randn(50, N) * 5
+        raw[0, 0] = 25.0                                  # softplus threshold branch
+        r = raw.clone().requires_grad_(True)
+        sp = torch.nn.Softplus()
+        mv = 1e-6
+        if head == 0: ref = r
+        elif head == 1: ref = sp(r)
+        elif head == 2: ref = sp(r) + 1
+        elif head == 3:
+            s_, u = torch.split(r, N // 2, dim=1); ref = torch.stack((s_, sp(u) + mv), dim=2).view(r.size())
+        elif head == 4:
+            s_, u = torch.split(r, N // 2, dim=1); ref = torch.stack((s_, sp(u)), dim=2).view(r.size())
+        elif head == 5:
+            s_, u = torch.split(r, N // 2, dim=1); ref = torch.stack((sp(s_) + mv, sp(u) + mv), dim=2).view(r.size())
+        else:
+            m_, l_, a_, b_ = torch.split(r, N // 4, dim=1)
+            ref = torch.stack((m_, sp(l_) + mv, sp(a_) + mv + 1, sp(b_) + mv), dim=2).view(r.size())
+        got = Fn.head_fwd(raw.cuda(), head)
+        close(got, ref, what=f"head {head}")
+        go = torch.randn(50, N)
+        ref.backward(go)
+        close(Fn.head_bwd(go.cuda(), raw.cuda(), head), r.grad, what=f"head bwd {head}")

@@ -1,0 +1,148 @@
+"""CPU-only checks of the host side: the native graph packer against the reference's own
+BatchMolGraph arrays (golden), the C-ABI library's exported symbols against include/*.h, the
+dropout stream against its numpy restatement, and the module surface (state_dict keys)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from reactranker_amd import _lib, featurization, synth
+from reactranker_amd.base_model import build_model
+from oracle import ref_cpu as O
+from oracle import dropout_ref
+from tests import helpers as Hh
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "reactranker_hip.h")).read()
+    declared = set(re.findall(r"\b(rr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"rr_dropout_keep"}            # mentioned in a comment only
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"symbols declared in the header but not exported: {missing}"
+    assert set(_lib.EXPORTED_SYMBOLS) == declared, (set(_lib.EXPORTED_SYMBOLS) ^ declared)
+    assert _lib.lib().rr_version() == _lib.ABI_VERSION
+    assert _lib.lib().rr_strerror(-1).decode().startswith("invalid argument")
+
+
+def test_ctypes_struct_layout_matches_compiled_header():
+    # rr_linear_args / rr_wgrad_args are passed by pointer; a size mismatch would corrupt fields silently
+    sl, sw = ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.lib().rr_abi_struct_sizes(ctypes.byref(sl), ctypes.byref(sw))
+    assert sl.value == ctypes.sizeof(_lib.LinearArgs)
+    assert sw.value == ctypes.sizeof(_lib.WgradArgs)
+
+
+@pytest.mark.parametrize("path", Hh.model_case_files(), ids=lambda p: p.split("model_")[-1][:-4])
+def test_native_packer_matches_reference_batchmolgraph(path):
+    d, cfg = Hh.load_case(path)
+    qb = Hh.case_queries(cfg)
+    for prefix, specs in (("r_", qb.r_specs), ("p_", qb.p_specs)):
+        b = featurization.BatchMolGraph(specs)
+        f_atoms, f_bonds, a2b, b2a, b2revb, a_scope, b_scope = b.get_components()
+        assert np.array_equal(f_atoms.numpy(), d[prefix + "f_atoms"])
+        assert np.array_equal(f_bonds.numpy(), d[prefix + "f_bonds"])
+        assert a2b.dtype == torch.int64 and np.array_equal(a2b.numpy(), d[prefix + "a2b"])
+        assert np.array_equal(b2a.numpy(), d[prefix + "b2a"])
+        assert np.array_equal(b2revb.numpy(), d[prefix + "b2revb"])
+        assert np.array_equal(b.get_a2a().numpy(), d[prefix + "a2a"])
+        assert np.array_equal(np.asarray(a_scope, np.int32).reshape(-1, 2), d[prefix + "a_scope"])
+        assert np.array_equal(np.asarray(b_scope, np.int32).reshape(-1, 2), d[prefix + "b_scope"])
+        assert b.max_num_bonds == int(d["K_" + prefix[0]])
+        # duck-typed (python list) molecules go through the other concat path and must agree
+        b2 = featurization.BatchMolGraph([synth.ListMolGraph(s) for s in specs])
+        for k in ("f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope", "a2b_rev_t", "b2t", "a2a_t", "npad",
+                  "atom2mol"):
+            assert np.array_equal(b._host[k], b2._host[k]), k
+
+
+def test_backward_tables_are_the_transposes():
+    qb = synth.make_queries(5, 3, [3, 4, 2], atoms_lo=4, atoms_hi=9)
+    b = featurization.BatchMolGraph(qb.p_specs, K=6)          # wider pad than needed (global-K case)
+    h = b._host
+    nA, nB, K = h["nA"], h["nB"], h["K"]
+    assert K == 6
+    rng = np.random.default_rng(0)
+    msg = rng.standard_normal((nB, 5))
+    # forward gather-sum over a2b (pad -> row 0), adjoint via tables
+    a_msg = msg[h["a2b"]].sum(1)
+    d_a = rng.standard_normal((nA, 5))
+    want = np.zeros_like(msg)
+    np.add.at(want, h["a2b"].reshape(-1), np.repeat(d_a, K, axis=0))
+    got = np.where(h["b2t"][:, None] >= 0, d_a[np.maximum(h["b2t"], 0)], 0.0)
+    got[0] += (h["npad"][:, None] * d_a).sum(0)
+    assert np.allclose(got, want)
+    # bond message m_in[b] = a_msg[b2a[b]] - msg[b2revb[b]] ; adjoint wrt a_msg via a2b_rev_t
+    d_min = rng.standard_normal((nB, 5))
+    want_a = np.zeros((nA, 5))
+    np.add.at(want_a, h["b2a"], d_min)
+    t = h["a2b_rev_t"]
+    got_a = np.where(t[..., None] >= 0, d_min[np.maximum(t, 0)], 0.0).sum(1)
+    assert np.allclose(got_a, want_a)
+    want_m = np.zeros((nB, 5))
+    np.add.at(want_m, h["b2revb"], -d_min)
+    assert np.allclose(-d_min[h["b2revb"]], want_m)
+    # a2a neighbour sums: adjoint via a2a_t + pad row
+    x = rng.standard_normal((nA, 5))
+    want_x = np.zeros_like(x)
+    np.add.at(want_x, h["a2a"].reshape(-1), np.repeat(d_a, K, axis=0))
+    t = h["a2a_t"]
+    got_x = np.where(t[..., None] >= 0, d_a[np.maximum(t, 0)], 0.0).sum(1)
+    got_x[0] += (h["npad"][:, None] * d_a).sum(0)
+    assert np.allclose(got_x, want_x)
+    assert h["atom2mol"][0] == -1 and (np.bincount(h["atom2mol"][1:]) == h["a_scope"][:, 1]).all()
+    assert a_msg.shape == (nA, 5)
+
+
+def test_pack_rejects_too_small_k_and_handles_empty():
+    qb = synth.make_queries(1, 1, [2])
+    with pytest.raises(RuntimeError):
+        featurization.BatchMolGraph(qb.p_specs, K=1)
+    b = featurization.BatchMolGraph([])
+    assert b.n_atoms == 1 and b.n_bonds == 1 and b.max_num_bonds == 1 and b.a_scope == []
+    # molecule without bonds: K = max(1, 0)
+    lone = synth.MolSpec(1, np.zeros((1, 61), np.float32), np.zeros((0, 2), np.int32), np.zeros((0, 22), np.float32))
+    b = featurization.BatchMolGraph([lone])
+    assert b.max_num_bonds == 1 and b.n_atoms == 2 and b.n_bonds == 1
+
+
+def test_dropout_stream_host_matches_numpy_restatement():
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    for p in (0.0, 0.1, 0.5, 0.9):
+        for seed in (0, 1, 0xDEADBEEFCAFEF00D):
+            idx = np.concatenate([np.arange(64), rng.integers(0, 2 ** 40, size=64)]).astype(np.uint64)
+            ref = dropout_ref.keep_mask(seed, idx, p)
+            got = np.array([L.rr_dropout_keep_host(seed, int(i), p) for i in idx], bool)
+            assert np.array_equal(ref, got)
+    big = dropout_ref.keep_mask(7, np.arange(200000, dtype=np.uint64), 0.1)
+    assert abs(big.mean() - 0.9) < 5e-3
+
+
+def test_module_surface_matches_reference_state_dict():
+    cfgs = [dict(hidden_size=300, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
+                 add_features_dim=1),
+            dict(hidden_size=32, mpnn_depth=1, mpnn_diff_depth=0, ffn_depth=1, use_bias=False, task_num=2,
+                 add_features_dim=0)]
+    for c in cfgs:
+        m = build_model(dropout=0.1, ffn_last_layer="with_softplus", **c)
+        want = O.model_shapes(c["hidden_size"], c["mpnn_depth"], c["mpnn_diff_depth"], c["ffn_depth"], c["task_num"],
+                              c["add_features_dim"], c["use_bias"])
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert got == want
+    m = build_model(hidden_size=300, task_num=1, add_features_dim=1, ffn_last_layer="with_softplus")
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 791101
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from reactranker_amd.loss import MLEloss
+    with pytest.raises(RuntimeError):
+        MLEloss()(torch.zeros(3), [3], torch.zeros(3), None)
