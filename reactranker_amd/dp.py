@@ -1,0 +1,72 @@
+"""Data-parallel glue: whole queries shard across ranks (one process per GPU), gradients are
+summed with ONE RCCL all-reduce of a flat fp32 bucket per step (torch.distributed backend "nccl"
+is RCCL on ROCm; xGMI underneath).  The reference has no distributed code at all (SURVEY.md
+section 2.1) — this is the north star's scaling path, not a port.
+
+Normalisation: ListMLE / evidential_ranking average over queries, ListNet
+and MSE over candidates, RankNet over pairs.  Each rank weights its local gradient by
+local_count / global_count so the reduced gradient equals the single-process one.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_queries(n_queries: int, rank: int, world: int):
+    """Contiguous block of whole queries for `rank` (never splits a list)."""
+    base, rem = divmod(n_queries, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradBucket:
+    """Flat fp32 gradient bucket (3.16 MB at H=300: latency-bound, so exactly one collective)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else "cpu"
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+
+    def allreduce(self, local_weight: float = 1.0, group=None) -> None:
+        """grad <- sum_ranks(local_weight_r * grad_r).  With equal shards pass 1/world."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            if local_weight != 1.0:
+                for p in self.params:
+                    if p.grad is not None:
+                        p.grad.mul_(local_weight)
+            return
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        if local_weight != 1.0:
+            self.flat.mul_(local_weight)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = self.flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+
+
+def loss_weight(kind: str, local_queries: int, global_queries: int, local_cands: int, global_cands: int,
+                local_pairs: Optional[int] = None, global_pairs: Optional[int] = None) -> float:
+    """Weight of this rank's gradient so the reduced gradient equals the single-process one."""
+    if kind in ("mle", "evidential_ranking"):
+        return local_queries / max(1, global_queries)
+    if kind in ("listnet", "mse", "regression", "gauss_regression"):
+        return local_cands / max(1, global_cands)
+    if kind == "ranknet":
+        return (local_pairs or 0) / max(1, global_pairs or 1)
+    raise ValueError(kind)

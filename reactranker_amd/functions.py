@@ -31,6 +31,42 @@ HEADS = {  # FFN task_type string -> rr_head (reference models/base_model.py:61-
 }
 
 
+class Profiler:
+    """Optional live timing of every launch of the heavy kernels with HIP events on the launch
+    stream (bench.py's roofline leg).  Off by default; records (kernel key, work, event pair)."""
+    enabled = False
+    records = []
+
+    @classmethod
+    def start(cls):
+        cls.enabled, cls.records = True, []
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        return cls.records
+
+
+class _Timed:
+    def __init__(self, key, flops, nbytes):
+        self.on = Profiler.enabled
+        if self.on:
+            self.key, self.flops, self.nbytes = key, flops, nbytes
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            Profiler.records.append((self.key, self.flops, self.nbytes, self.e0, self.e1))
+        return False
+
+
 def _rowmajor(t: torch.Tensor, name: str) -> torch.Tensor:
     """float32 CUDA tensor whose rows are contiguous (row stride >= row length); copies otherwise
     (e.g. the stride-0 expanded gradients autograd hands to backward)."""
@@ -61,8 +97,10 @@ def gather_sum(src: torch.Tensor, idx: torch.Tensor, H: int, out: torch.Tensor =
     n_out, K = (idx.shape[0], idx.shape[1]) if idx.dim() == 2 else (idx.shape[0], 1)
     if out is None:
         out = _new(src, n_out, H)
-    check(lib().rr_gather_sum_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), n_out, K, H, ptr(out), _ld(out),
-                                  stream()), "rr_gather_sum_f32")
+    # algorithmic bytes: every source row once, every output row once, the index table once
+    with _Timed("gather_sum_kernel", 0, 4 * (src.shape[0] * H + n_out * H + n_out * K)):
+        check(lib().rr_gather_sum_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), n_out, K, H, ptr(out), _ld(out),
+                                      stream()), "rr_gather_sum_f32")
     return out
 
 
@@ -104,7 +142,13 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.act, A.drop_p, A.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
     A.c, A.ldc = ptr(out), _ld(out)
     A.c_pre, A.ld_pre = ptr(c_pre), _ld(c_pre)
-    check(lib().rr_linear_f32(C.byref(A), stream()), "rr_linear_f32")
+    nt = 4 if N <= 64 else (10 if N <= 160 else 19)
+    mode = 2 if a_mask is not None else (1 if a1_sub is not None else 0)
+    kk = k1 + k2
+    nbytes = 4 * (M * kk * (2 if (a1_sub is not None or a_mask is not None) else 1) + N * kk + M * N *
+                  (1 + (residual is not None) + (c_pre is not None)))
+    with _Timed(f"linear_kernel<{nt},{mode}>", 2 * M * N * kk, nbytes):
+        check(lib().rr_linear_f32(C.byref(A), stream()), "rr_linear_f32")
     return out
 
 
@@ -125,7 +169,8 @@ def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=N
     A.dbias = ptr(dbias)
     A.accumulate = int(accumulate)
     A.workspace, A.workspace_bytes = ptr(ws), nbytes
-    check(lib().rr_linear_wgrad_f32(C.byref(A), stream()), "rr_linear_wgrad_f32")
+    with _Timed("wgrad_kernel", 2 * M * N * (K + 1), 4 * (M * N * (2 if mask is not None else 1) + M * K + N * K)):
+        check(lib().rr_linear_wgrad_f32(C.byref(A), stream()), "rr_linear_wgrad_f32")
     return dw
 
 

@@ -47,8 +47,11 @@ def check_grads(model, d, prefix, H, tol=5e-5):
         ref = d[key]
         g = torch.zeros_like(p) if p.grad is None else p.grad
         got = Hh.sample_like(g.detach().cpu().numpy(), H)
-        s = max(1e-3, float(np.abs(ref).max()))
-        close(got / s, ref / s, tol=tol, what=key)
+        # relative to the tensor's largest entry, plus 1e-6 absolute for gradients that are
+        # analytically zero (e.g. ListMLE's output bias: sum_j dL/ds_j = 0 per list)
+        err = float(np.max(np.abs(got.astype(np.float64) - ref)))
+        bound = tol * float(np.abs(ref).max()) + 1e-6
+        assert err <= bound, f"{key}: |err| {err:.3e} > {bound:.3e}"
     assert seen > 0, prefix
 
 
@@ -197,8 +200,9 @@ def test_train_mode_dropout_matches_oracle_with_same_masks(cfgname, p, golden_di
         gr = torch.zeros_like(P[k]) if gr is None else gr
         g = got[k].grad
         g = torch.zeros_like(got[k]) if g is None else g
-        s = max(1e-3, float(gr.abs().max()))
-        close(g / s, gr / s, tol=1e-4, what="train grad " + k)
+        err = float((g.detach().cpu() - gr).abs().max())
+        bound = 1e-4 * float(gr.abs().max()) + 1e-6      # + absolute floor for analytically-zero gradients
+        assert err <= bound, f"train grad {k}: |err| {err:.3e} > {bound:.3e}"
 
 
 def test_reference_style_batch_objects_and_checkpoint_roundtrip(tmp_path, golden_dir):

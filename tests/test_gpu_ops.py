@@ -66,10 +66,15 @@ def test_weighted_colsum(n):
     out = torch.full((300,), 2.0, device="cuda")
     Fn.weighted_colsum(dev(x), dev(w), 300, out, accumulate=True)
     ref = 2.0 + (w[:, None].astype(np.float64) * x).sum(0)
-    close(out, ref, tol=2e-5, what="colsum")
+    # fp32 summation bound: a few ulps of the column's L1 norm (the sums themselves can be ~0)
+    l1 = (w[:, None] * np.abs(x)).sum(0).astype(np.float64)
+    assert np.all(np.abs(out.cpu().numpy() - ref) <= 1e-6 * l1 + 1e-5), "weighted colsum"
     out2 = torch.empty(300, device="cuda")
     Fn.weighted_colsum(dev(x), None, 300, out2, accumulate=False)
-    close(out2, x.astype(np.float64).sum(0), tol=2e-5)
+    assert np.all(np.abs(out2.cpu().numpy() - x.astype(np.float64).sum(0)) <= 1e-6 * np.abs(x).sum(0) + 1e-5)
+    out3 = torch.empty(300, device="cuda")
+    Fn.weighted_colsum(dev(x), None, 300, out3, accumulate=False)
+    assert torch.equal(out2, out3)                       # fixed-order reduction: run-to-run identical
 
 
 def _ref_linear(a, w, bias, res, act):
