@@ -103,7 +103,8 @@ typedef struct rr_linear_args {
   const float* a1_sub;   int64_t lda1_sub;            const int32_t* a1_sub_idx;
   const float* a2;       int64_t lda2;      int k2;
   const float* a_mask;   int64_t ld_mask;   float mask_scale;
-  const float* w;        int64_t ldw;               /* [N, k1+k2] row-major */
+  const float* w;        int64_t ldw;               /* [N, k1+k2] row-major (nn.Linear.weight), or */
+  int w_packed;                                     /* 1: the zero-padded layout of rr_pack_weight_f32 */
   const float* bias;                                /* [N] or NULL */
   const float* residual; int64_t ldr;               /* [M, N] or NULL */
   int act;                                          /* rr_act */
@@ -115,6 +116,16 @@ typedef struct rr_linear_args {
 } rr_linear_args;
 
 int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream);
+
+/* Packed weight layout for the straight-line fast path of rr_linear_f32:
+ *   dst[r, 0:k1] = L[r, 0:k1];  dst[r, r16(k1) : r16(k1)+k2] = L[r, k1:k1+k2];  zeros elsewhere;
+ *   row stride rr_packed_weight_ld(k1,k2) = r16(k1) + r16(k2), r16 = round up to 16;
+ *   L[r, c] = src[r*ld_src + c0 + c]            (transpose = 0: a column slice of the weight)
+ *           = src[c*ld_src + c0 + r]            (transpose = 1: its transpose, for dX = dZ * W)
+ * Weights change every optimizer step, so the mirror re-packs them once per forward. */
+int64_t rr_packed_weight_ld(int k1, int k2);
+int rr_pack_weight_f32(const float* src, int64_t ld_src, int transpose, int rows, int c0, int k1, int k2,
+                       float* dst, rr_stream_t stream);
 
 /* dW[n, k] (+)= sum_m dZ[m,n] * X[m,k],   dbias[n] (+)= sum_m dZ[m,n]
  * dZ[m,n] = dy[m,n] * (mask ? (mask[m,n] > 0) * mask_scale : 1);  X = [X1 | X2] described

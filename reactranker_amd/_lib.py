@@ -29,7 +29,7 @@ class LinearArgs(C.Structure):
         ("a1_sub", c_f32p), ("lda1_sub", i64), ("a1_sub_idx", c_i32p),
         ("a2", c_f32p), ("lda2", i64), ("k2", i32),
         ("a_mask", c_f32p), ("ld_mask", i64), ("mask_scale", f32),
-        ("w", c_f32p), ("ldw", i64),
+        ("w", c_f32p), ("ldw", i64), ("w_packed", i32),
         ("bias", c_f32p),
         ("residual", c_f32p), ("ldr", i64),
         ("act", i32), ("drop_p", f32), ("drop_seed", u64),
@@ -62,6 +62,8 @@ _SIGS = {
     "rr_colsum_workspace_bytes": (C.c_size_t, [i64, i32]),
     "rr_weighted_colsum_f32": (i32, [c_f32p, i64, i64, c_f32p, i32, c_f32p, i32, C.c_void_p, C.c_size_t, c_stream]),
     "rr_linear_f32": (i32, [C.POINTER(LinearArgs), c_stream]),
+    "rr_packed_weight_ld": (i64, [i32, i32]),
+    "rr_pack_weight_f32": (i32, [c_f32p, i64, i32, i32, i32, i32, i32, c_f32p, c_stream]),
     "rr_linear_wgrad_workspace_bytes": (C.c_size_t, [i64, i32, i32]),
     "rr_linear_wgrad_f32": (i32, [C.POINTER(WgradArgs), c_stream]),
     "rr_dropout_keep_host": (i32, [u64, u64, f32]),

@@ -31,8 +31,11 @@ enum : int {
   F_A1_VEC = 1, F_A2_VEC = 2, F_SUB_VEC = 4, F_MASK_VEC = 8, F_W1_VEC = 16, F_W2_VEC = 32, F_EPI_VEC = 64, F_PRE_VEC = 128
 };
 
+__host__ __device__ constexpr int r16(int k) { return (k + 15) & ~15; }
+
 struct LinearParams {
   rr_linear_args a;
+  int w_k1_off;         // column of W where segment 2 starts (k1, or r16(k1) for packed weights)
   int t1, t2;           // k-tiles of segment 1 / 2
   int flags;
   uint32_t drop_thr;
@@ -134,7 +137,7 @@ __global__ void __launch_bounds__(THREADS) linear_kernel(const LinearParams P) {
     if (wr >= BN || n >= a.N) return f32x4(0.f);
     const float* wp = a.w + static_cast<int64_t>(n) * a.ldw;
     if (kt < P.t1) return load_chunk(wp, kt * BK + skq * 4, a.k1, flags & F_W1_VEC);
-    return load_chunk(wp + a.k1, (kt - P.t1) * BK + skq * 4, a.k2, flags & F_W2_VEC);
+    return load_chunk(wp + P.w_k1_off, (kt - P.t1) * BK + skq * 4, a.k2, flags & F_W2_VEC);
   };
   auto store_tile = [&](int buf, const f32x4& ra, const f32x4 (&rb)[B_ITERS]) {
     float* As = lds[buf];
@@ -245,6 +248,197 @@ __global__ void __launch_bounds__(THREADS) linear_kernel(const LinearParams P) {
       for (int e = 0; e < 4; ++e)
         if (n + e < a.N) crow[n + e] = v[e];
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------ fast path
+// Same math as linear_kernel, for the hot case: every A source 16-byte addressable and W in
+// the packed layout of rr_pack_weight_f32 ([N][r16(k1) + r16(k2)], zero padded).  The loader
+// is straight-line code: W needs no bounds logic at all (row index clamped, pad columns are
+// zeros), A chunks are loaded unconditionally from (valid ? row + k : dummy), and every
+// fix-up (tail columns, invalid rows, the subtraction / ReLU mask of MODE 1 / 2) happens when
+// the registers are written to LDS, i.e. AFTER the k-tile's MFMAs.  Nothing uses a loaded
+// value before that point, so the compiler keeps all loads of tile t+1 in flight across the
+// whole MFMA block of tile t (the generic kernel waits on each load as it is issued).
+template <int NT, int MODE>
+__global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearParams P) {
+  constexpr int BN = 16 * NT;
+  constexpr int B_ITERS = (BN * 4 + THREADS - 1) / THREADS;
+  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BK];
+
+  const rr_linear_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
+  const int n0 = blockIdx.y * BN;
+
+  const int srow = tid >> 2, skq = tid & 3;
+  const int64_t sm = m0 + srow;
+  const float* const dummy = a.w;                     // any valid, 16-byte aligned address
+  const float* rowp1 = nullptr;
+  const float* rowp2 = nullptr;
+  const float* subp = nullptr;                        // MODE 1: subtract source, MODE 2: mask source
+  if (sm < a.M) {
+    if (a.k1 > 0) {
+      if (a.a1_idx) {
+        const int32_t j = a.a1_idx[sm];
+        if (j >= 0) rowp1 = a.a1 + static_cast<int64_t>(j) * a.lda1;
+      } else {
+        rowp1 = a.a1 + sm * a.lda1;
+      }
+      if (MODE == 1 && a.a1_sub) {
+        if (a.a1_sub_idx) {
+          const int32_t j = a.a1_sub_idx[sm];
+          if (j >= 0) subp = a.a1_sub + static_cast<int64_t>(j) * a.lda1_sub;
+        } else {
+          subp = a.a1_sub + sm * a.lda1_sub;
+        }
+      }
+      if (MODE == 2) subp = a.a_mask + sm * a.ld_mask;
+    }
+    if (a.k2 > 0) rowp2 = a.a2 + sm * a.lda2;
+  }
+  // W rows staged by this thread (row index clamped into [0, N-1]: columns >= N are never stored)
+  const float* wrow[B_ITERS];
+#pragma unroll
+  for (int it = 0; it < B_ITERS; ++it) {
+    int n = n0 + ((it * THREADS + tid) >> 2);
+    if (n > a.N - 1) n = a.N - 1;
+    wrow[it] = a.w + static_cast<int64_t>(n) * a.ldw + skq * 4;
+  }
+  const int k1p = r16(a.k1);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4(0.f);
+
+  const int nk = P.t1 + P.t2;
+  f32x4 ra, rs;
+  f32x4 rb[B_ITERS];
+
+  auto issue = [&](int kt) {                          // pure loads, no arithmetic on the results
+    const bool seg1 = kt < P.t1;
+    const int kl = (seg1 ? kt : kt - P.t1) * BK + skq * 4;
+    const float* p = seg1 ? rowp1 : rowp2;
+    const int ks = seg1 ? a.k1 : a.k2;
+    ra = ld4((p != nullptr && kl < ks) ? p + kl : dummy);
+    if (MODE != 0) rs = ld4((seg1 && subp != nullptr && kl < ks) ? subp + kl : dummy);
+    const int kw = seg1 ? kt * BK : k1p + (kt - P.t1) * BK;
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) rb[it] = ld4(wrow[it] + kw);
+  };
+  auto commit = [&](int kt, int buf) {                // fix-ups + LDS stores (first use of the loads)
+    const bool seg1 = kt < P.t1;
+    const int kl = (seg1 ? kt : kt - P.t1) * BK + skq * 4;
+    const float* p = seg1 ? rowp1 : rowp2;
+    const int ks = seg1 ? a.k1 : a.k2;
+    const bool ok = (p != nullptr);
+    f32x4 v;
+    v.x = (ok && kl + 0 < ks) ? ra.x : 0.f;
+    v.y = (ok && kl + 1 < ks) ? ra.y : 0.f;
+    v.z = (ok && kl + 2 < ks) ? ra.z : 0.f;
+    v.w = (ok && kl + 3 < ks) ? ra.w : 0.f;
+    if (MODE == 1) {
+      const bool oks = seg1 && (subp != nullptr);
+      v.x -= (oks && kl + 0 < ks) ? rs.x : 0.f;
+      v.y -= (oks && kl + 1 < ks) ? rs.y : 0.f;
+      v.z -= (oks && kl + 2 < ks) ? rs.z : 0.f;
+      v.w -= (oks && kl + 3 < ks) ? rs.w : 0.f;
+    }
+    if (MODE == 2) {
+      const bool oks = seg1 && (subp != nullptr);
+      v.x = (oks && kl + 0 < ks && rs.x > 0.f) ? v.x * a.mask_scale : 0.f;
+      v.y = (oks && kl + 1 < ks && rs.y > 0.f) ? v.y * a.mask_scale : 0.f;
+      v.z = (oks && kl + 2 < ks && rs.z > 0.f) ? v.z * a.mask_scale : 0.f;
+      v.w = (oks && kl + 3 < ks && rs.w > 0.f) ? v.w * a.mask_scale : 0.f;
+    }
+    float* As = lds[buf];
+    float* Bs = lds[buf] + BM * BK;
+    *reinterpret_cast<f32x4*>(As + srow * BK + 4 * swz(srow, skq)) = v;
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      const int wr = (it * THREADS + tid) >> 2;
+      if (wr < BN) *reinterpret_cast<f32x4*>(Bs + wr * BK + 4 * swz(wr, skq)) = rb[it];
+    }
+  };
+
+  issue(0);
+  commit(0, 0);
+  __syncthreads();
+
+  const int fr = lane & 15, fkq = lane >> 4;
+  const int a_off = (wave * 16 + fr) * BK + 4 * swz(fr, fkq);
+  const int b_off = fr * BK + 4 * swz(fr, fkq);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) issue(kt + 1);
+    const float* As = lds[cur];
+    const float* Bs = lds[cur] + BM * BK;
+    const f32x4 af = ld4(As + a_off);
+    constexpr int G = 5;
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += G) {
+      f32x4 wf[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (t0 + g < NT) wf[g] = ld4(Bs + (t0 + g) * 16 * BK + b_off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (t0 + g < NT) acc[t0 + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][j], af[j], acc[t0 + g], 0, 0, 0);
+      }
+    }
+    if (more) commit(kt + 1, cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (vector form only: the fast path requires F_EPI_VEC)
+  const int64_t m = m0 + wave * 16 + fr;
+  if (m >= a.M) return;
+  const int nq = fkq * 4;
+  float* crow = a.c + m * a.ldc;
+  const float* rrow = a.residual ? a.residual + m * a.ldr : nullptr;
+  float* prow = a.c_pre ? a.c_pre + m * a.ld_pre : nullptr;
+#pragma unroll
+  for (int tc = 0; tc < NT; ++tc) {
+    const int n = n0 + tc * 16 + nq;
+    if (n >= a.N) continue;
+    f32x4 v = acc[tc];
+    if (a.bias) v = v + ld4(a.bias + n);
+    if (rrow) v = v + ld4(rrow + n);
+    if (prow) *reinterpret_cast<f32x4*>(prow + n) = v;
+    if (a.act == RR_ACT_RELU) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    if (P.drop_thr != 0u) {
+      const uint64_t base = static_cast<uint64_t>(m) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rr_keep(a.drop_seed, base + e, P.drop_thr) ? v[e] * P.keep_scale : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(crow + n) = v;
+  }
+}
+
+// dst = zero-padded packed copy of a weight (or of its transpose) for the fast path
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ src, int64_t ld_src, int transpose,
+                                                          int rows, int c0, int k1, int k2, float* __restrict__ dst) {
+  const int k1p = r16(k1), ldd = r16(k1) + r16(k2);
+  const int64_t total = static_cast<int64_t>(rows) * ldd;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int r = static_cast<int>(e / ldd), c = static_cast<int>(e - static_cast<int64_t>(r) * ldd);
+    int lc = -1;                                      // logical column
+    if (c < k1) lc = c;
+    else if (c >= k1p && c - k1p < k2) lc = k1 + (c - k1p);
+    float v = 0.f;
+    if (lc >= 0) v = transpose ? src[static_cast<int64_t>(lc) * ld_src + c0 + r] : src[static_cast<int64_t>(r) * ld_src + c0 + lc];
+    dst[e] = v;
   }
 }
 
@@ -457,12 +651,18 @@ void wgrad_plan(int64_t M, int N, int k1, int k2, WgradParams* P) {
 }
 
 template <int NT>
-int launch_linear(const LinearParams& P, hipStream_t s) {
+int launch_linear(const LinearParams& P, hipStream_t s, bool fast) {
   const rr_linear_args& a = P.a;
   dim3 grid(static_cast<unsigned>((a.M + BM - 1) / BM), static_cast<unsigned>((a.N + 16 * NT - 1) / (16 * NT)));
-  if (a.a_mask) linear_kernel<NT, 2><<<grid, THREADS, 0, s>>>(P);
-  else if (a.a1_sub) linear_kernel<NT, 1><<<grid, THREADS, 0, s>>>(P);
-  else linear_kernel<NT, 0><<<grid, THREADS, 0, s>>>(P);
+  if (fast) {
+    if (a.a_mask) linear_fast_kernel<NT, 2><<<grid, THREADS, 0, s>>>(P);
+    else if (a.a1_sub) linear_fast_kernel<NT, 1><<<grid, THREADS, 0, s>>>(P);
+    else linear_fast_kernel<NT, 0><<<grid, THREADS, 0, s>>>(P);
+  } else {
+    if (a.a_mask) linear_kernel<NT, 2><<<grid, THREADS, 0, s>>>(P);
+    else if (a.a1_sub) linear_kernel<NT, 1><<<grid, THREADS, 0, s>>>(P);
+    else linear_kernel<NT, 0><<<grid, THREADS, 0, s>>>(P);
+  }
   return rr_launch_status();
 }
 
@@ -476,7 +676,8 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   RR_CHECK_ARG(args);
   const rr_linear_args& a = *args;
   RR_CHECK_ARG(a.M >= 0 && a.N >= 1 && a.k1 >= 0 && a.k2 >= 0 && a.k1 + a.k2 >= 1);
-  RR_CHECK_ARG(a.w && a.c && a.ldw >= a.k1 + a.k2 && a.ldc >= a.N);
+  RR_CHECK_ARG(a.w && a.c && a.ldc >= a.N);
+  RR_CHECK_ARG(a.w_packed ? (a.ldw == r16(a.k1) + r16(a.k2) && rr_aligned16(a.w)) : (a.ldw >= a.k1 + a.k2));
   RR_CHECK_ARG(a.k1 == 0 || (a.a1 && a.lda1 >= a.k1));
   RR_CHECK_ARG(a.k2 == 0 || (a.a2 && a.lda2 >= a.k2));
   RR_CHECK_ARG(!a.a1_sub || (a.k1 > 0 && a.lda1_sub >= a.k1));
@@ -509,10 +710,30 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   P.keep_scale = 1.0f / (1.0f - a.drop_p);
 
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a.N <= 64) return launch_linear<4>(P, s);
-  if (a.N <= 160) return launch_linear<10>(P, s);
-  return launch_linear<19>(P, s);
+  // fast path: packed W, every present A source 16-byte addressable, vector epilogue
+  bool fast = a.w_packed && (P.flags & F_EPI_VEC) && (!a.c_pre || (P.flags & F_PRE_VEC));
+  if (a.k1 > 0 && !(P.flags & F_A1_VEC)) fast = false;
+  if (a.k2 > 0 && !(P.flags & F_A2_VEC)) fast = false;
+  if (a.a1_sub && !(P.flags & F_SUB_VEC)) fast = false;
+  if (a.a_mask && !(P.flags & F_MASK_VEC)) fast = false;
+  // the generic kernel reads packed weights too: segment 2 simply starts at column r16(k1)
+  P.w_k1_off = a.w_packed ? r16(a.k1) : a.k1;
+  if (a.w_packed) P.flags |= F_W1_VEC | F_W2_VEC;
+  if (a.N <= 64) return launch_linear<4>(P, s, fast);
+  if (a.N <= 160) return launch_linear<10>(P, s, fast);
+  return launch_linear<19>(P, s, fast);
 }
+
+int rr_pack_weight_f32(const float* src, int64_t ld_src, int transpose, int rows, int c0, int k1, int k2, float* dst,
+                       rr_stream_t stream) {
+  RR_CHECK_ARG(src && dst && rows >= 1 && c0 >= 0 && k1 >= 0 && k2 >= 0 && k1 + k2 >= 1 && ld_src >= 1);
+  const int64_t total = static_cast<int64_t>(rows) * (r16(k1) + r16(k2));
+  pack_weight_kernel<<<rr_grid_for(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(src, ld_src, transpose, rows,
+                                                                                           c0, k1, k2, dst);
+  return rr_launch_status();
+}
+
+int64_t rr_packed_weight_ld(int k1, int k2) { return r16(k1) + r16(k2); }
 
 size_t rr_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
   if (M < 0 || N < 1 || K < 1) return 0;

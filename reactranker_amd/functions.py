@@ -125,7 +125,8 @@ def weighted_colsum(x, w, H: int, out, accumulate: bool):
 
 
 def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub_idx=None, a2=None, k2=0, a_mask=None,
-           mask_scale=1.0, ldw=None, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0, out=None, c_pre=None):
+           mask_scale=1.0, ldw=None, w_packed=False, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0,
+           out=None, c_pre=None):
     """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h)."""
     ref = a1 if a1 is not None else a2
     if out is None:
@@ -136,7 +137,7 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.a1_sub, A.lda1_sub, A.a1_sub_idx = ptr(a1_sub), _ld(a1_sub), ptr(a1_sub_idx)
     A.a2, A.lda2, A.k2 = ptr(a2), _ld(a2), k2
     A.a_mask, A.ld_mask, A.mask_scale = ptr(a_mask), _ld(a_mask), float(mask_scale)
-    A.w, A.ldw = ptr(w), (w.stride(0) if ldw is None else ldw)
+    A.w, A.ldw, A.w_packed = ptr(w), (w.stride(0) if ldw is None else ldw), int(w_packed)
     A.bias = ptr(bias)
     A.residual, A.ldr = ptr(residual), _ld(residual)
     A.act, A.drop_p, A.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -147,7 +148,8 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     kk = k1 + k2
     nbytes = 4 * (M * kk * (2 if (a1_sub is not None or a_mask is not None) else 1) + N * kk + M * N *
                   (1 + (residual is not None) + (c_pre is not None)))
-    with _Timed(f"linear_kernel<{nt},{mode}>", 2 * M * N * kk, nbytes):
+    kern = "linear_fast_kernel" if w_packed else "linear_kernel"
+    with _Timed(f"{kern}<{nt},{mode}>", 2 * M * N * kk, nbytes):
         check(lib().rr_linear_f32(C.byref(A), stream()), "rr_linear_f32")
     return out
 
@@ -198,7 +200,7 @@ def dropout(x, p: float, seed: int, out=None):
 
 
 def segment_mean_fwd(x, g, H: int, feat, F: int, drop_p: float, seed: int):
-    out = _new(x, g.M, H + F)
+    out = _new(x, g.M, (H + F + 3) // 4 * 4)[:, :H + F]          # rows padded to 16 bytes for the fast GEMM path
     check(lib().rr_segment_mean_fwd_f32(ptr(x), _ld(x), ptr(g.a_scope), g.M, H, ptr(feat), F, float(drop_p),
                                         int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(out), _ld(out), stream()),
           "rr_segment_mean_fwd_f32")
@@ -235,11 +237,26 @@ class LinW:
         self.b = None if bias is None else _rowmajor(bias.detach(), "bias")
         self._t = {}
 
-    def t(self, c0: int, c1: int):
-        """(W[:, c0:c1])^T, contiguous [c1-c0, N] — the `w` of dX = dZ * W."""
-        key = (c0, c1)
+    def pk(self, k1: int, k2: int = 0):
+        """Zero-padded packed copy of W = [W1 | W2] (rr_pack_weight_f32) for the fast GEMM path."""
+        key = ("f", k1, k2)
         if key not in self._t:
-            self._t[key] = self.w[:, c0:c1].t().contiguous()
+            n = self.w.shape[0]
+            dst = torch.empty(n, int(lib().rr_packed_weight_ld(k1, k2)), dtype=torch.float32, device=self.w.device)
+            check(lib().rr_pack_weight_f32(ptr(self.w), self.w.stride(0), 0, n, 0, k1, k2, ptr(dst), stream()),
+                  "rr_pack_weight_f32")
+            self._t[key] = dst
+        return self._t[key]
+
+    def pk_t(self, c0: int, c1: int):
+        """Packed (W[:, c0:c1])^T — the weight operand of dX = dZ * W[:, c0:c1]."""
+        key = ("t", c0, c1)
+        if key not in self._t:
+            n = self.w.shape[0]
+            dst = torch.empty(c1 - c0, int(lib().rr_packed_weight_ld(n, 0)), dtype=torch.float32, device=self.w.device)
+            check(lib().rr_pack_weight_f32(ptr(self.w), self.w.stride(0), 1, c1 - c0, c0, n, 0, ptr(dst), stream()),
+                  "rr_pack_weight_f32")
+            self._t[key] = dst
         return self._t[key]
 
     def grads(self):
@@ -257,17 +274,17 @@ def mpn_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p
     nA, nB = g.nA, g.nB
     inp = _new(g.f_bonds, nB, H)
     msg = _new(g.f_bonds, nB, H)
-    linear(nB, H, Wi.w, a1=g.f_bonds, k1=FBOND, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp)          # :80-81
+    linear(nB, H, Wi.pk(FBOND), w_packed=True, a1=g.f_bonds, k1=FBOND, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp)          # :80-81
     msgs, amsgs = [msg], []
     for it in range(depth - 1):                                                                      # :84
         a_msg = gather_sum(msgs[-1], g.a2b, H)                                                       # :89-90
-        new = linear(nB, H, Wh.w, a1=a_msg, k1=H, a1_idx=g.b2a, a1_sub=msgs[-1], a1_sub_idx=g.b2revb,
+        new = linear(nB, H, Wh.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=g.b2a, a1_sub=msgs[-1], a1_sub_idx=g.b2revb,
                      bias=Wh.b, residual=inp, act=ACT_RELU, drop_p=p, seed=_site_seed(seed, it))     # :91-97
         amsgs.append(a_msg)
         msgs.append(new)
     del inp
     a_last = gather_sum(msgs[-1], g.a2b, H)                                                          # :101-102
-    h = linear(nA, H, Wo.w, a1=g.f_atoms, k1=ATOM_FDIM, a2=a_last, k2=H, bias=Wo.b, act=ACT_RELU, drop_p=p,
+    h = linear(nA, H, Wo.pk(ATOM_FDIM, H), w_packed=True, a1=g.f_atoms, k1=ATOM_FDIM, a2=a_last, k2=H, bias=Wo.b, act=ACT_RELU, drop_p=p,
                seed=_site_seed(seed, 1000))                                                          # :103-105
     return h, (msgs, amsgs, a_last, h)
 
@@ -289,7 +306,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
     gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
     # atom_hiddens = drop(relu([f_atoms | a_last] W_o^T + b_o))
     wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H)
-    d_a = linear(nA, H, Wo.t(ATOM_FDIM, ATOM_FDIM + H), a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
+    d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
     # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)]
     d_msg = gather_sum(d_a, g.b2t, H)
     _pad_row_fix(d_msg, d_a, g, H)
@@ -303,7 +320,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
             d_inp = dz
         wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
               accumulate=(it != depth - 2))
-        d_min = linear(nB, H, Wh.t(0, H), a1=dz, k1=H)
+        d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
         d_a = gather_sum(d_min, g.a2b_rev_t, H)                     # sum over the atom's outgoing bonds
         d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H, out=d_msg)
         _pad_row_fix(d_msg, d_a, g, H)
@@ -326,7 +343,7 @@ def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Opt
     inp = _new(x, nA, H)
     msg = _new(x, nA, H)
     first_p = p if depth == 0 else 0.0                                                   # :221 (depth 0: dropout(message))
-    linear(nA, H, Wi.w, a1=x, k1=Hin, a1_sub=x_sub, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp,
+    linear(nA, H, Wi.pk(Hin), w_packed=True, a1=x, k1=Hin, a1_sub=x_sub, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp,
            drop_p=first_p, seed=_site_seed(seed, 2000))                                  # :194-195
     msgs, amsgs = [msg], []
     a_last = None
@@ -334,12 +351,12 @@ def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Opt
         fb = g.fb_sum() if depth > 1 else None
         for it in range(depth - 1):                                                      # :199
             a_msg = gather_sum(msgs[-1], g.a2a, H)                                       # :201
-            new = linear(nA, H, Wh.w, a1=a_msg, k1=H, a2=fb, k2=FBOND, bias=Wh.b, residual=inp, act=ACT_RELU,
+            new = linear(nA, H, Wh.pk(H, FBOND), w_packed=True, a1=a_msg, k1=H, a2=fb, k2=FBOND, bias=Wh.b, residual=inp, act=ACT_RELU,
                          drop_p=p, seed=_site_seed(seed, 2001 + it))                     # :202-213
             amsgs.append(a_msg)
             msgs.append(new)
         a_last = gather_sum(msgs[-1], g.a2a, H)                                          # :215-216
-        hid = linear(nA, H, Wo.w, a1=x, k1=Hin, a1_sub=x_sub, a2=a_last, k2=H, bias=Wo.b, act=ACT_RELU, drop_p=p,
+        hid = linear(nA, H, Wo.pk(Hin, H), w_packed=True, a1=x, k1=Hin, a1_sub=x_sub, a2=a_last, k2=H, bias=Wo.b, act=ACT_RELU, drop_p=p,
                      seed=_site_seed(seed, 3000))                                        # :217-219
     else:
         hid = msg
@@ -363,8 +380,8 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
     if depth > 0:
         wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x2=a_last, k2=H)
         # dX over both column segments of W_o: [d_x | d_a]
-        d_x = linear(nA, Hin, Wo.t(0, Hin), a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
-        d_a = linear(nA, H, Wo.t(Hin, Hin + H), a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
+        d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
+        d_a = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
         d_msg = gather_sum(d_a, g.a2a_t, H)                        # neighbour relation is symmetric
         _pad_row_fix(d_msg, d_a, g, H)
         d_inp, dz = None, None
@@ -375,7 +392,7 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
             if d_inp is None:
                 d_inp = dz
             wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2))
-            d_a = linear(nA, H, Wh.t(0, H), a1=dz, k1=H)
+            d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
             d_msg = gather_sum(d_a, g.a2a_t, H, out=d_msg)
             _pad_row_fix(d_msg, d_a, g, H)
         if d_inp is None:
@@ -387,9 +404,9 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
         d_inp = relu_bwd(d_hid, msgs[0], ks)                        # hid = drop(relu(inp))
     wgrad(nA, H, d_inp, gWi, dbias=gbi, x1=x, k1=Hin, x1_sub=x_sub)
     if d_x is None:
-        d_x = linear(nA, Hin, Wi.t(0, Hin), a1=d_inp, k1=H)
+        d_x = linear(nA, Hin, Wi.pk_t(0, Hin), w_packed=True, a1=d_inp, k1=H)
     else:
-        linear(nA, Hin, Wi.t(0, Hin), a1=d_inp, k1=H, residual=d_x, out=d_x)
+        linear(nA, Hin, Wi.pk_t(0, Hin), w_packed=True, a1=d_inp, k1=H, residual=d_x, out=d_x)
     return d_x, gWi, gbi, gWh, gbh, gWo, gbo
 
 
@@ -399,10 +416,10 @@ def ffn_forward(x, layers: List[LinW], p: float, seed: int, head: int):
     M = x.shape[0]
     hs = [x]
     for li, L in enumerate(layers[:-1]):
-        hs.append(linear(M, L.w.shape[0], L.w, a1=hs[-1], k1=hs[-1].shape[1], bias=L.b, act=ACT_RELU, drop_p=p,
+        hs.append(linear(M, L.w.shape[0], L.pk(L.w.shape[1]), w_packed=True, a1=hs[-1], k1=L.w.shape[1], bias=L.b, act=ACT_RELU, drop_p=p,
                          seed=_site_seed(seed, 4000 + li)))
     L = layers[-1]
-    raw = linear(M, L.w.shape[0], L.w, a1=hs[-1], k1=hs[-1].shape[1], bias=L.b)
+    raw = linear(M, L.w.shape[0], L.pk(L.w.shape[1]), w_packed=True, a1=hs[-1], k1=L.w.shape[1], bias=L.b)
     out = raw if head == 0 else head_fwd(raw, head)
     return out, (hs, raw)
 
@@ -415,19 +432,19 @@ def ffn_backward(layers: List[LinW], p: float, head: int, saved, dout, need_dx: 
     d = dout if head == 0 else head_bwd(dout, raw, head)
     L = layers[-1]
     gw, gb = L.grads()
-    wgrad(M, L.w.shape[0], d, gw, dbias=gb, x1=hs[-1], k1=hs[-1].shape[1])
+    wgrad(M, L.w.shape[0], d, gw, dbias=gb, x1=hs[-1], k1=L.w.shape[1])
     grads.append((gw, gb))
     dx = None
     if len(layers) > 1 or need_dx:
-        dx = linear(M, hs[-1].shape[1], L.t(0, hs[-1].shape[1]), a1=d, k1=L.w.shape[0])
+        dx = linear(M, L.w.shape[1], L.pk_t(0, L.w.shape[1]), w_packed=True, a1=d, k1=L.w.shape[0])
     for li in reversed(range(len(layers) - 1)):
         L = layers[li]
         gw, gb = L.grads()
         y = hs[li + 1]                                              # drop(relu(.)) output of this layer
-        wgrad(M, L.w.shape[0], dx, gw, dbias=gb, mask=y, mask_scale=ks, x1=hs[li], k1=hs[li].shape[1])
+        wgrad(M, L.w.shape[0], dx, gw, dbias=gb, mask=y, mask_scale=ks, x1=hs[li], k1=L.w.shape[1])
         grads.append((gw, gb))
         if li > 0 or need_dx:
-            dx = linear(M, hs[li].shape[1], L.t(0, hs[li].shape[1]), a1=dx, k1=L.w.shape[0], a_mask=y, mask_scale=ks)
+            dx = linear(M, L.w.shape[1], L.pk_t(0, L.w.shape[1]), w_packed=True, a1=dx, k1=L.w.shape[0], a_mask=y, mask_scale=ks)
     grads.reverse()
     return dx, grads
 
