@@ -599,6 +599,180 @@ __global__ void __launch_bounds__(THREADS) wgrad_kernel(const WgradParams P) {
   }
 }
 
+
+// ------------------------------------------------------------------------ wgrad fast path
+// Straight-line loader for the hot case (every operand 16-byte addressable).  A 16-row tile is
+// 640 dZ chunks + 640 X chunks of 16 bytes; thread t owns dZ chunks {t, t+256, t+512 (t<128)}
+// and the same three X chunks, so every slot's role is known at compile time.  Loads are
+// unconditional from (valid ? address : dummy); tail masks, the ReLU mask, the subtraction and
+// the ones column are applied when the registers go to LDS, after the tile's MFMAs.  Gather
+// indices are fetched one tile ahead (row clamped, so the load itself is unconditional); the
+// validity of a gathered row (index >= 0) is latched at issue time.
+template <bool HAS_MASK, bool HAS_SUB>
+__global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParams P) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2 * WMT * WLD];
+  const rr_wgrad_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bn = blockIdx.x / P.nblk_k, bk = blockIdx.x % P.nblk_k;
+  const int nb = bn * WBN, kb = bk * WBN;
+  const int64_t mbeg = static_cast<int64_t>(blockIdx.y) * P.rows_per_chunk;
+  int64_t mend = mbeg + P.rows_per_chunk;
+  if (mend > a.M) mend = a.M;
+  const int K = a.k1 + a.k2;
+  const float* const dummy = a.dy;
+  constexpr int S = 3;                                  // slots per operand per thread
+  const bool slot2 = tid < 640 - 2 * THREADS;           // the third slot exists for t < 128 (waves 0-1)
+  const int64_t mlast = a.M - 1;
+
+  int srow[S], scol[S], xkind[S], xcol[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const int g = tid + i * THREADS;
+    srow[i] = g / 40;
+    scol[i] = (g - srow[i] * 40) * 4;
+    const int k = kb + scol[i];
+    xkind[i] = 0;                                       // 1 = segment 1, 2 = segment 2 (+ ones column), 0 = nothing
+    xcol[i] = 0;
+    if (k < a.k1) { xkind[i] = 1; xcol[i] = k; }
+    else if (k >= P.k1p && k < P.kext) { xkind[i] = 2; xcol[i] = k - P.k1p; }
+  }
+
+  f32x4 zv[S], zm[S], xv[S], xs[S];
+  bool xok[S], sok[S];
+  int32_t ia[S], is[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) { ia[i] = 0; is[i] = 0; }
+
+  auto fetch_idx = [&](int64_t mt) {
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      int64_t mrow = mt + srow[i];
+      if (mrow > mlast) mrow = mlast;
+      if (a.x1_idx) ia[i] = a.x1_idx[mrow];
+      if (HAS_SUB) { if (a.x1_sub_idx) is[i] = a.x1_sub_idx[mrow]; }
+    }
+  };
+  auto issue = [&](int64_t mt) {
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      const int64_t mrow = mt + srow[i];
+      const bool rowok = (mrow < mend) && (i < 2 || slot2);
+      const int n = nb + scol[i];
+      const bool zok = rowok && n < a.N;
+      zv[i] = ld4(zok ? a.dy + mrow * a.ld_dy + n : dummy);
+      if (HAS_MASK) zm[i] = ld4(zok ? a.mask + mrow * a.ld_mask + n : dummy);
+      const float* p = dummy;
+      const float* q = dummy;
+      bool vx = false, vs = false;
+      if (xkind[i] == 1) {
+        const int64_t j = a.x1_idx ? static_cast<int64_t>(ia[i]) : mrow;
+        vx = rowok && j >= 0;
+        if (vx) p = a.x1 + j * a.ldx1 + xcol[i];
+        if (HAS_SUB) {
+          const int64_t js = a.x1_sub_idx ? static_cast<int64_t>(is[i]) : mrow;
+          vs = rowok && js >= 0;
+          if (vs) q = a.x1_sub + js * a.ldx1_sub + xcol[i];
+        }
+      } else if (xkind[i] == 2) {
+        vx = rowok && xcol[i] < a.k2;
+        if (vx) p = a.x2 + mrow * a.ldx2 + xcol[i];
+      }
+      xok[i] = vx;
+      sok[i] = vs;
+      xv[i] = ld4(p);
+      if (HAS_SUB) xs[i] = ld4(q);
+    }
+  };
+  auto commit = [&](int64_t mt, int buf) {
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      if (i == 2 && !slot2) continue;
+      const bool rowok = (mt + srow[i]) < mend;
+      const int n = nb + scol[i];
+      const int xlim = xkind[i] == 1 ? a.k1 : a.k2;
+      f32x4 z, x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = (rowok && n + e < a.N) ? zv[i][e] : 0.f;
+        if (HAS_MASK) t = (rowok && n + e < a.N && zm[i][e] > 0.f) ? t * a.mask_scale : 0.f;
+        z[e] = t;
+        float u = (xok[i] && xcol[i] + e < xlim) ? xv[i][e] : 0.f;
+        if (HAS_SUB) u -= (sok[i] && xcol[i] + e < xlim) ? xs[i][e] : 0.f;
+        if (xkind[i] == 2 && rowok && a.k2 - xcol[i] == e) u = 1.0f;   // ones column -> bias gradient
+        x[e] = u;
+      }
+      *reinterpret_cast<f32x4*>(&lds[buf][srow[i] * WLD + scol[i]]) = z;
+      *reinterpret_cast<f32x4*>(&lds[buf][WMT * WLD + srow[i] * WLD + scol[i]]) = x;
+    }
+  };
+
+  f32x4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = f32x4(0.f);
+
+  const int wn = (wave >> 1) * (WT * 16), wk = (wave & 1) * (WT * 16);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int64_t ntiles = (mend > mbeg) ? (mend - mbeg + WMT - 1) / WMT : 0;
+  if (ntiles > 0) {
+    fetch_idx(mbeg);
+    issue(mbeg);
+    fetch_idx(mbeg + WMT);
+    commit(mbeg, 0);
+  }
+  __syncthreads();
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int cur = static_cast<int>(t & 1);
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      issue(mbeg + (t + 1) * WMT);                      // uses the indices fetched one tile ago
+      fetch_idx(mbeg + (t + 2) * WMT);
+    }
+    const float* Zs = lds[cur];
+    const float* Xs = lds[cur] + WMT * WLD;
+#pragma unroll
+    for (int kk = 0; kk < WMT / 4; ++kk) {
+      float zf[WT], xf[WT];
+      const int row = kk * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        zf[i] = Zs[row * WLD + wn + i * 16 + fr];
+        xf[i] = Xs[row * WLD + wk + i * 16 + fr];
+      }
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) commit(mbeg + (t + 1) * WMT, cur ^ 1);
+    __syncthreads();
+  }
+
+  float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(blockIdx.y) * P.slab;
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int kx = kb + wk + j * 16 + fr;
+      if (kx >= P.kext) continue;
+      int kreal = -1;
+      if (kx < a.k1) kreal = kx;
+      else if (kx >= P.k1p && kx < P.k1p + a.k2) kreal = a.k1 + (kx - P.k1p);
+      else if (kx == P.k1p + a.k2) kreal = -2;
+      if (kreal == -1) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = nb + wn + i * 16 + fq * 4 + e;
+        if (n >= a.N) continue;
+        if (kreal >= 0) slab[static_cast<int64_t>(n) * K + kreal] = acc[i][j][e];
+        else slab[static_cast<int64_t>(a.N) * K + n] = acc[i][j][e];
+      }
+    }
+  }
+}
+
 // fixed-order sum of the chunk slabs into dw / dbias
 __global__ void __launch_bounds__(THREADS) wgrad_reduce_kernel(const float* __restrict__ ws, int nchunks, int64_t slab,
                                                                int N, int K, float* __restrict__ dw, int64_t ld_dw,
@@ -765,7 +939,19 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
   if (vec_ok(a.dy, a.ld_dy)) P.flags |= F_EPI_VEC;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(static_cast<unsigned>(P.nblk_n * P.nblk_k), static_cast<unsigned>(P.nchunks));
-  wgrad_kernel<<<grid, THREADS, 0, s>>>(P);
+  bool fast = (P.flags & F_EPI_VEC) != 0;
+  if (a.mask && !(P.flags & F_MASK_VEC)) fast = false;
+  if (a.k1 > 0 && !(P.flags & F_A1_VEC)) fast = false;
+  if (a.k2 > 0 && !(P.flags & F_A2_VEC)) fast = false;
+  if (a.x1_sub && !(P.flags & F_SUB_VEC)) fast = false;
+  if (fast) {
+    if (a.mask && a.x1_sub) wgrad_fast_kernel<true, true><<<grid, THREADS, 0, s>>>(P);
+    else if (a.mask) wgrad_fast_kernel<true, false><<<grid, THREADS, 0, s>>>(P);
+    else if (a.x1_sub) wgrad_fast_kernel<false, true><<<grid, THREADS, 0, s>>>(P);
+    else wgrad_fast_kernel<false, false><<<grid, THREADS, 0, s>>>(P);
+  } else {
+    wgrad_kernel<<<grid, THREADS, 0, s>>>(P);
+  }
   const int64_t total = P.slab;
   wgrad_reduce_kernel<<<static_cast<unsigned>((total + THREADS - 1) / THREADS), THREADS, 0, s>>>(
       static_cast<const float*>(a.workspace), P.nchunks, P.slab, a.N, K, a.dw, a.ld_dw, a.dbias, a.accumulate);
