@@ -103,6 +103,10 @@ typedef struct rr_linear_args {
   const float* a1_sub;   int64_t lda1_sub;            const int32_t* a1_sub_idx;
   const float* a2;       int64_t lda2;      int k2;
   const float* a_mask;   int64_t ld_mask;   float mask_scale;
+  float* dz_out;         int64_t ld_dz;     int dz_accumulate;  /* with a_mask: also materialise the masked operand,
+                                                       dz_out[m,k] (+)= A[m,k] — e.g. d_input += dZ of every
+                                                       message-passing step (the residual `input +` of mpn.py:95).
+                                                       Needs k1 % 4 == 0, 16-byte aligned rows, N <= 304. */
   const float* w;        int64_t ldw;               /* [N, k1+k2] row-major (nn.Linear.weight), or */
   int w_packed;                                     /* 1: the zero-padded layout of rr_pack_weight_f32 */
   const float* bias;                                /* [N] or NULL */
@@ -158,7 +162,7 @@ int rr_dropout_keep_host(uint64_t seed, uint64_t index, float p);
  * mask stream; the same call on a gradient is its backward.  (FFN input dropout, models/base_model.py:32-36.) */
 int rr_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out, rr_stream_t stream);
 
-/* dz = dy * (y > 0) * scale;  if acc != NULL: acc += dz.   (ReLU + inverted-dropout backward;
+/* dz = dy * (y > 0) * scale (dz may be NULL when only the accumulation is wanted);  if acc != NULL: acc += dz.   (ReLU + inverted-dropout backward;
  * y is the layer's stored post-dropout output, so y > 0 <=> kept and active.) */
 int rr_relu_bwd_f32(const float* dy, const float* y, float scale, float* dz, float* acc,
                     int64_t n, rr_stream_t stream);

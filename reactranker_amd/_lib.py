@@ -29,6 +29,7 @@ class LinearArgs(C.Structure):
         ("a1_sub", c_f32p), ("lda1_sub", i64), ("a1_sub_idx", c_i32p),
         ("a2", c_f32p), ("lda2", i64), ("k2", i32),
         ("a_mask", c_f32p), ("ld_mask", i64), ("mask_scale", f32),
+        ("dz_out", c_f32p), ("ld_dz", i64), ("dz_accumulate", i32),
         ("w", c_f32p), ("ldw", i64), ("w_packed", i32),
         ("bias", c_f32p),
         ("residual", c_f32p), ("ldr", i64),

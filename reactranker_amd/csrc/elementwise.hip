@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__
     r.y = v.y > 0.f ? g.y * scale : 0.f;
     r.z = v.z > 0.f ? g.z * scale : 0.f;
     r.w = v.w > 0.f ? g.w * scale : 0.f;
-    reinterpret_cast<f32x4*>(dz)[i] = r;
+    if (dz) reinterpret_cast<f32x4*>(dz)[i] = r;
     if (acc) {
       f32x4 a = reinterpret_cast<f32x4*>(acc)[i];
       reinterpret_cast<f32x4*>(acc)[i] = a + r;
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__
   }
   for (int64_t i = n4 * 4 + t0; i < n; i += stride) {   // tail
     const float r = y[i] > 0.f ? dy[i] * scale : 0.f;
-    dz[i] = r;
+    if (dz) dz[i] = r;
     if (acc) acc[i] += r;
   }
 }
@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) relu_bwd_scalar_kernel(const float* __res
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float r = y[i] > 0.f ? dy[i] * scale : 0.f;
-    dz[i] = r;
+    if (dz) dz[i] = r;
     if (acc) acc[i] += r;
   }
 }
@@ -164,10 +164,10 @@ int rr_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out
 
 int rr_relu_bwd_f32(const float* dy, const float* y, float scale, float* dz, float* acc, int64_t n,
                     rr_stream_t stream) {
-  RR_CHECK_ARG(dy && y && dz && n >= 0);
+  RR_CHECK_ARG(dy && y && (dz || acc) && n >= 0);
   if (n == 0) return RR_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool vec = rr_aligned16(dy) && rr_aligned16(y) && rr_aligned16(dz) && (!acc || rr_aligned16(acc));
+  const bool vec = rr_aligned16(dy) && rr_aligned16(y) && (!dz || rr_aligned16(dz)) && (!acc || rr_aligned16(acc));
   if (vec) {
     relu_bwd_kernel<<<rr_grid_for((n + 3) / 4, 256), 256, 0, s>>>(dy, y, scale, dz, acc, n / 4, n);
   } else {

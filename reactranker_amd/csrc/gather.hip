@@ -74,36 +74,57 @@ __global__ void __launch_bounds__(256) gather_diff_kernel(const float* __restric
   }
 }
 
-// stage 1 of the deterministic weighted column sum: block b sums its row chunk.
-__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, int64_t n, int64_t ld,
+// stage 1 of the deterministic weighted column sum: block b sums its row chunk.  256 threads =
+// RL row-lanes x CG column groups of 4 floats (H = 300 -> 75 groups x 3 row-lanes), so every lane
+// issues 16-byte loads; the row-lanes are combined through LDS in a fixed order.
+template <int VEC>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, int64_t n, int64_t ldx,
                                                              const float* __restrict__ w, int H,
                                                              int64_t rows_per_block, float* __restrict__ partial) {
+  __shared__ float red[256 * VEC];
+  using V = typename Vec<VEC>::T;
+  const int CG = (H + VEC - 1) / VEC;                  // column groups
   const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
-  for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int64_t r = r0;
-    for (; r + 4 <= r1; r += 4) {
-      const float w0 = w ? w[r] : 1.f, w1 = w ? w[r + 1] : 1.f, w2 = w ? w[r + 2] : 1.f, w3 = w ? w[r + 3] : 1.f;
-      a0 += w0 * x[r * ld + c];
-      a1 += w1 * x[(r + 1) * ld + c];
-      a2 += w2 * x[(r + 2) * ld + c];
-      a3 += w3 * x[(r + 3) * ld + c];
+  for (int c0 = 0; c0 < CG; c0 += 256) {               // H <= 1024 floats in one pass for VEC = 4
+    const int ncg = min(CG - c0, 256);
+    const int RL = 256 / ncg;                          // row lanes
+    const int rl = threadIdx.x / ncg, cg = threadIdx.x - rl * ncg;
+    V a0 = V(0.f), a1 = V(0.f);
+    if (rl < RL) {
+      const float* xp = x + (c0 + cg) * VEC;
+      int64_t r = r0 + rl;
+      for (; r + RL < r1; r += 2 * RL) {               // two independent rows in flight
+        const float w0 = w ? w[r] : 1.f, w1 = w ? w[r + RL] : 1.f;
+        a0 = a0 + ld<VEC>(xp + r * ldx) * w0;
+        a1 = a1 + ld<VEC>(xp + (r + RL) * ldx) * w1;
+      }
+      if (r < r1) a0 = a0 + ld<VEC>(xp + r * ldx) * (w ? w[r] : 1.f);
+      a0 = a0 + a1;
     }
-    for (; r < r1; ++r) a0 += (w ? w[r] : 1.f) * x[r * ld + c];
-    partial[static_cast<int64_t>(blockIdx.x) * H + c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl < RL) st<VEC>(&red[threadIdx.x * VEC], a0);
+    __syncthreads();
+    if (rl == 0) {
+      V acc = ld<VEC>(&red[cg * VEC]);
+      for (int k = 1; k < RL; ++k) acc = acc + ld<VEC>(&red[(k * ncg + cg) * VEC]);
+      st<VEC>(partial + static_cast<int64_t>(blockIdx.x) * (CG * VEC) + (c0 + cg) * VEC, acc);
+    }
   }
 }
 
-// stage 2: fixed-order sum over the block partials.
-__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int nblocks, int H,
+// stage 2: one wavefront per column sums the block partials (lane-strided, then a shuffle tree:
+// fixed order, run-to-run identical).
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int nblocks, int Hp, int H,
                                                            float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c >= H) return;
   float acc = 0.f;
-  for (int b = 0; b < nblocks; ++b) acc += partial[static_cast<int64_t>(b) * H + c];
-  out[c] = accumulate ? out[c] + acc : acc;
+  for (int b = lane; b < nblocks; b += 64) acc += partial[static_cast<int64_t>(b) * Hp + c];
+  acc = rr_wave_sum(acc);
+  if (lane == 0) out[c] = accumulate ? out[c] + acc : acc;
 }
 
 // out[m, 0:H] = mean of x rows [start, start+size); out[m, H:H+F] = feat[m]; optional dropout.
@@ -196,15 +217,15 @@ int rr_gather_diff_f32(const float* a, int64_t n_a, int64_t ld_a, const int32_t*
 }
 
 static int colsum_blocks(int64_t n) {
-  int64_t b = (n + 255) / 256;   // >= 256 rows per block
+  int64_t b = (n + 127) / 128;   // >= 128 rows per block
   if (b < 1) b = 1;
-  if (b > 1024) b = 1024;
+  if (b > 512) b = 512;
   return static_cast<int>(b);
 }
 
 size_t rr_colsum_workspace_bytes(int64_t n, int H) {
   if (n < 0 || H < 1) return 0;
-  return static_cast<size_t>(colsum_blocks(n)) * static_cast<size_t>(H) * sizeof(float);
+  return static_cast<size_t>(colsum_blocks(n)) * static_cast<size_t>((H + 3) / 4 * 4) * sizeof(float);
 }
 
 int rr_weighted_colsum_f32(const float* x, int64_t n, int64_t ld, const float* w, int H, float* out, int accumulate,
@@ -213,10 +234,14 @@ int rr_weighted_colsum_f32(const float* x, int64_t n, int64_t ld, const float* w
   if (workspace_bytes < rr_colsum_workspace_bytes(n, H)) return RR_ERR_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nb = colsum_blocks(n);
-  const int64_t rpb = (n + nb - 1) / nb;
+  int64_t rpb = (n + nb - 1) / nb;
+  if (rpb < 1) rpb = 1;
   float* partial = static_cast<float*>(workspace);
-  colsum_partial_kernel<<<nb, 256, 0, s>>>(x, n, ld, w, H, rpb > 0 ? rpb : 1, partial);
-  colsum_final_kernel<<<(H + 255) / 256, 256, 0, s>>>(partial, nb, H, out, accumulate);
+  const bool vec = (H % 4 == 0) && (ld % 4 == 0) && rr_aligned16(x) && rr_aligned16(workspace);
+  const int Hp = (H + 3) / 4 * 4;
+  if (vec) colsum_partial_kernel<4><<<nb, 256, 0, s>>>(x, n, ld, w, H, rpb, partial);
+  else colsum_partial_kernel<1><<<nb, 256, 0, s>>>(x, n, ld, w, H, rpb, partial);
+  colsum_final_kernel<<<(H + 3) / 4, 256, 0, s>>>(partial, nb, vec ? Hp : H, H, out, accumulate);
   return rr_launch_status();
 }
 

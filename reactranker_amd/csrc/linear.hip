@@ -298,6 +298,8 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
     }
     if (a.k2 > 0) rowp2 = a.a2 + sm * a.lda2;
   }
+  float* dzrow = nullptr;                             // MODE 2 side output: dz_out (+)= masked operand
+  if (MODE == 2 && a.dz_out && sm < a.M && blockIdx.y == 0) dzrow = a.dz_out + sm * a.ld_dz;
   // W rows staged by this thread (row index clamped into [0, N-1]: columns >= N are never stored)
   const float* wrow[B_ITERS];
 #pragma unroll
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
   for (int i = 0; i < NT; ++i) acc[i] = f32x4(0.f);
 
   const int nk = P.t1 + P.t2;
-  f32x4 ra, rs;
+  f32x4 ra, rs, rc;
   f32x4 rb[B_ITERS];
 
   auto issue = [&](int kt) {                          // pure loads, no arithmetic on the results
@@ -323,6 +325,9 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
     const int ks = seg1 ? a.k1 : a.k2;
     ra = ld4((p != nullptr && kl < ks) ? p + kl : dummy);
     if (MODE != 0) rs = ld4((seg1 && subp != nullptr && kl < ks) ? subp + kl : dummy);
+    if (MODE == 2) {
+      if (a.dz_accumulate) rc = ld4((dzrow != nullptr && kl < ks) ? dzrow + kl : dummy);
+    }
     const int kw = seg1 ? kt * BK : k1p + (kt - P.t1) * BK;
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it) rb[it] = ld4(wrow[it] + kw);
@@ -351,6 +356,8 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
       v.y = (oks && kl + 1 < ks && rs.y > 0.f) ? v.y * a.mask_scale : 0.f;
       v.z = (oks && kl + 2 < ks && rs.z > 0.f) ? v.z * a.mask_scale : 0.f;
       v.w = (oks && kl + 3 < ks && rs.w > 0.f) ? v.w * a.mask_scale : 0.f;
+      if (dzrow != nullptr && kl < ks)                  // k1 % 4 == 0: the chunk is whole
+        *reinterpret_cast<f32x4*>(dzrow + kl) = a.dz_accumulate ? v + rc : v;
     }
     float* As = lds[buf];
     float* Bs = lds[buf] + BM * BK;
@@ -858,6 +865,7 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   RR_CHECK_ARG(!a.a_mask || (a.k2 == 0 && !a.a1_sub && !a.a1_idx && a.ld_mask >= a.k1));
   RR_CHECK_ARG(!a.residual || a.ldr >= a.N);
   RR_CHECK_ARG(!a.c_pre || a.ld_pre >= a.N);
+  RR_CHECK_ARG(!a.dz_out || (a.a_mask && a.ld_dz >= a.k1));
   RR_CHECK_ARG(a.act == RR_ACT_NONE || a.act == RR_ACT_RELU);
   RR_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f);
   RR_CHECK_ARG(a.M < (int64_t(1) << 31) * BM);
@@ -893,6 +901,9 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   // the generic kernel reads packed weights too: segment 2 simply starts at column r16(k1)
   P.w_k1_off = a.w_packed ? r16(a.k1) : a.k1;
   if (a.w_packed) P.flags |= F_W1_VEC | F_W2_VEC;
+  if (a.dz_out) {                                     // side output only exists on the straight-line path
+    if (!fast || a.k1 % 4 != 0 || !vec_ok(a.dz_out, a.ld_dz)) return RR_ERR_ALIGN;
+  }
   if (a.N <= 64) return launch_linear<4>(P, s, fast);
   if (a.N <= 160) return launch_linear<10>(P, s, fast);
   return launch_linear<19>(P, s, fast);

@@ -143,7 +143,9 @@ class DeviceGraph:
         (reference models/mpn.py:202-209).  Input-only, so it is computed once per batch and cached."""
         if self._fb_sum is None:
             from . import functions as Fn
-            self._fb_sum = Fn.gather_sum(self.f_bonds, self.a2b, BOND_FDIM + ATOM_FDIM)
+            w = BOND_FDIM + ATOM_FDIM
+            buf = torch.zeros(self.nA, self.f_bonds.shape[1], dtype=torch.float32, device=self.device)  # ld 84
+            self._fb_sum = Fn.gather_sum(self.f_bonds, self.a2b, w, out=buf)
         return self._fb_sum
 
 

@@ -126,7 +126,7 @@ def weighted_colsum(x, w, H: int, out, accumulate: bool):
 
 def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub_idx=None, a2=None, k2=0, a_mask=None,
            mask_scale=1.0, ldw=None, w_packed=False, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0,
-           out=None, c_pre=None):
+           out=None, c_pre=None, dz_out=None, dz_accumulate=False):
     """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h)."""
     ref = a1 if a1 is not None else a2
     if out is None:
@@ -137,6 +137,7 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.a1_sub, A.lda1_sub, A.a1_sub_idx = ptr(a1_sub), _ld(a1_sub), ptr(a1_sub_idx)
     A.a2, A.lda2, A.k2 = ptr(a2), _ld(a2), k2
     A.a_mask, A.ld_mask, A.mask_scale = ptr(a_mask), _ld(a_mask), float(mask_scale)
+    A.dz_out, A.ld_dz, A.dz_accumulate = ptr(dz_out), _ld(dz_out), int(dz_accumulate)
     A.w, A.ldw, A.w_packed = ptr(w), (w.stride(0) if ldw is None else ldw), int(w_packed)
     A.bias = ptr(bias)
     A.residual, A.ldr = ptr(residual), _ld(residual)
@@ -176,8 +177,8 @@ def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=N
     return dw
 
 
-def relu_bwd(dy, y, scale: float, dz=None, acc=None):
-    if dz is None:
+def relu_bwd(dy, y, scale: float, dz=None, acc=None, want_dz=True):
+    if dz is None and want_dz:
         dz = torch.empty_like(y)
     check(lib().rr_relu_bwd_f32(ptr(dy), ptr(y), float(scale), ptr(dz), ptr(acc), y.numel(), stream()),
           "rr_relu_bwd_f32")
@@ -311,16 +312,26 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
     d_msg = gather_sum(d_a, g.b2t, H)
     _pad_row_fix(d_msg, d_a, g, H)
     d_inp = None
+    fused = (H % 4 == 0)                                             # ReLU backward fused into the GEMM operand loads
     dz = None
     for it in reversed(range(depth - 1)):
         # msgs[it+1] = drop(relu(inp + m_in W_h^T + b_h)),  m_in = amsgs[it][b2a] - msgs[it][b2revb]
-        buf = torch.empty_like(d_msg) if (dz is None or dz is d_inp) else dz
-        dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
-        if d_inp is None:
-            d_inp = dz
-        wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
-              accumulate=(it != depth - 2))
-        d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
+        first = d_inp is None
+        if fused:
+            if first:
+                d_inp = torch.empty_like(d_msg)
+            wgrad(nB, H, d_msg, gWh, dbias=gbh, mask=msgs[it + 1], mask_scale=ks, x1=amsgs[it], k1=H, x1_idx=g.b2a,
+                  x1_sub=msgs[it], x1_sub_idx=g.b2revb, accumulate=(it != depth - 2))
+            d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
+                           dz_out=d_inp, dz_accumulate=not first)    # d_inp (+)= dZ on the way through
+        else:
+            buf = torch.empty_like(d_msg) if (dz is None or dz is d_inp) else dz
+            dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
+            if first:
+                d_inp = dz
+            wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it],
+                  x1_sub_idx=g.b2revb, accumulate=(it != depth - 2))
+            d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
         d_a = gather_sum(d_min, g.a2b_rev_t, H)                     # sum over the atom's outgoing bonds
         d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H, out=d_msg)
         _pad_row_fix(d_msg, d_a, g, H)
@@ -328,8 +339,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
     if d_inp is None:
         d_inp = relu_bwd(d_msg, msgs[0], 1.0)
     else:
-        buf = dz if dz is not d_inp else torch.empty_like(d_msg)
-        relu_bwd(d_msg, msgs[0], 1.0, dz=buf, acc=d_inp)
+        relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
     wgrad(nB, H, d_inp, gWi, dbias=gbi, x1=g.f_bonds, k1=FBOND)
     return gWi, gbi, gWh, gbh, gWo, gbo
 
@@ -385,21 +395,30 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
         d_msg = gather_sum(d_a, g.a2a_t, H)                        # neighbour relation is symmetric
         _pad_row_fix(d_msg, d_a, g, H)
         d_inp, dz = None, None
+        fused = (H % 4 == 0)
         fb = g.fb_sum() if depth > 1 else None
         for it in reversed(range(depth - 1)):
-            buf = torch.empty_like(d_msg) if (dz is None or dz is d_inp) else dz
-            dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
-            if d_inp is None:
-                d_inp = dz
-            wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2))
-            d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
+            first = d_inp is None
+            if fused:
+                if first:
+                    d_inp = torch.empty_like(d_msg)
+                wgrad(nA, H, d_msg, gWh, dbias=gbh, mask=msgs[it + 1], mask_scale=ks, x1=amsgs[it], k1=H, x2=fb,
+                      k2=FBOND, accumulate=(it != depth - 2))
+                d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
+                             dz_out=d_inp, dz_accumulate=not first)
+            else:
+                buf = torch.empty_like(d_msg) if (dz is None or dz is d_inp) else dz
+                dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
+                if first:
+                    d_inp = dz
+                wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2))
+                d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
             d_msg = gather_sum(d_a, g.a2a_t, H, out=d_msg)
             _pad_row_fix(d_msg, d_a, g, H)
         if d_inp is None:
             d_inp = relu_bwd(d_msg, msgs[0], 1.0)
         else:
-            buf = dz if dz is not d_inp else torch.empty_like(d_msg)
-            relu_bwd(d_msg, msgs[0], 1.0, dz=buf, acc=d_inp)
+            relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
     else:
         d_inp = relu_bwd(d_hid, msgs[0], ks)                        # hid = drop(relu(inp))
     wgrad(nA, H, d_inp, gWi, dbias=gbi, x1=x, k1=Hin, x1_sub=x_sub)
