@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libreactranker_hip.so")
+LIB_PATH = os.environ.get("RR_LIB_PATH") or os.path.join(_HERE, "csrc", "libreactranker_hip.so")   # override: A/B builds
 
 c_f32p = C.c_void_p
 c_i32p = C.c_void_p
