@@ -267,7 +267,12 @@ def reaction_forward(P, cfg, r_graph, p_graph, add_features=None, masks=None, fa
     r_h = mpn_forward(P, r, cfg["depth"], masks=masks, p=p, tag="r")       # :155
     p_h = mpn_forward(P, pg, cfg["depth"], masks=masks, p=p, tag="p")      # :156
     diff = p_h - r_h                                                       # :168
-    fb = None if add_features is None else _t(np.asarray(add_features), torch.float32)
+    if add_features is None:
+        fb = None
+    elif torch.is_tensor(add_features):
+        fb = add_features                                    # caller chose the dtype (fp64 identity checks)
+    else:
+        fb = _t(np.asarray(add_features), torch.float32)
     vecs = mpn_diff_forward(P, diff, pg, cfg["diff_depth"], fb, masks=masks, p=p, faithful=faithful)
     out = ffn_forward(P, vecs, cfg["ffn_depth"], cfg["task_type"], masks=masks, p=p)   # :169
     if return_parts:

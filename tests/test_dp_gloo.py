@@ -1,0 +1,114 @@
+"""Data-parallel path on CPU: 2 processes over gloo (the GPU job uses the same code with the
+"nccl" = RCCL backend).  Proves SURVEY.md section 8e: with the per-loss weights of
+reactranker_amd.dp.loss_weight, the all-reduced gradient equals the single-process gradient for
+every loss normalisation (per-query mean, per-candidate mean, per-pair mean), with ragged shards.
+The math runs on the CPU oracle here (the HIP kernels need a GPU); what is under test is the
+sharding + bucket + weighting logic that bench.py and a trainer use."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as O
+from reactranker_amd import synth
+from reactranker_amd.dp import GradBucket, loss_weight, shard_queries
+
+CFG = dict(depth=2, diff_depth=2, ffn_depth=2, task_type="no_softplus")
+SCOPE = [5, 3, 7, 2, 6]          # ragged lists; shards get 3 and 2 queries
+H = 16
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _loss(kind, out, scope, targets):
+    if kind == "mle":
+        return O.listmle_loss(out, scope, targets).sum(), None
+    if kind == "listnet":
+        return O.listnet_loss(out, scope, targets), None
+    if kind == "mse":
+        return O.mse_loss(out, targets), None
+    ls, pairs = O.ranknet_sum_session(out, scope, targets, 1.0)
+    return ls, pairs
+
+
+def _grads(kind, w, qb, lo, hi, K):
+    m0, m1 = sum(qb.scope[:lo]), sum(qb.scope[:hi])
+    # fp64 so the identity under test (weighting / sharding) is not blurred by fp32 summation order
+    P = {k: v.double().requires_grad_(v.requires_grad) for k, v in O.params_from_numpy(w, requires_grad=True).items()}
+    names = [k for k in P if P[k].requires_grad]
+
+    def g64(specs):
+        g = O.graph_tensors(O.pack_batch(specs, K=K))
+        g["f_atoms"], g["f_bonds"] = g["f_atoms"].double(), g["f_bonds"].double()
+        return g
+    out = O.reaction_forward(P, CFG, g64(qb.r_specs[m0:m1]), g64(qb.p_specs[m0:m1]),
+                             torch.tensor(qb.add_features[m0:m1]).double())
+    loss, pairs = _loss(kind, out, qb.scope[lo:hi], torch.tensor(qb.targets[m0:m1]).double())
+    if kind == "ranknet":
+        loss = loss / max(pairs, 1.0)            # train_pairwise.py:147 (per accumulation window)
+    g = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
+    return names, [torch.zeros_like(P[k]) if x is None else x for k, x in zip(names, g)], pairs, (m1 - m0)
+
+
+def _worker(rank, world, port, kind, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        shapes = O.model_shapes(H, 2, 2, 2, 1, 1, True)
+        w = synth.seeded_weights(shapes, 3)
+        qb = synth.make_queries(99, len(SCOPE), SCOPE, atoms_lo=4, atoms_hi=8)
+        K = 4                                                    # global pad width on every rank (hazard H1)
+        names, full, pairs_all, m_all = _grads(kind, w, qb, 0, len(SCOPE), K)
+        lo, hi = shard_queries(len(SCOPE), rank, world)
+        _, local, pairs_loc, m_loc = _grads(kind, w, qb, lo, hi, K)
+        params = [torch.nn.Parameter(torch.zeros_like(g, dtype=torch.float32)) for g in local]
+        for p, g in zip(params, local):
+            p.grad = g.float()                                   # the bucket itself is fp32, like the GPU job's
+        wgt = loss_weight(kind, hi - lo, len(SCOPE), m_loc, m_all, pairs_loc, pairs_all)
+        GradBucket(params).allreduce(wgt)
+        # relative to each tensor's largest entry, with an absolute floor for gradients that are analytically
+        # zero (ListMLE's output bias: sum_j dL/ds_j = 0 per list -> pure rounding noise)
+        err = max(float((p.grad.double() - f).abs().max() / (f.abs().max() + 1e-6)) for p, f in zip(params, full))
+        ret[rank] = err
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["mle", "listnet", "mse", "ranknet"])
+def test_weighted_allreduce_equals_single_process_gradient(kind):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r] < 1e-5, (kind, dict(ret))      # only the bucket's fp32 rounding remains
+
+
+def test_shard_queries_covers_everything_without_splitting():
+    for n in (1, 5, 8, 13, 64):
+        for world in (1, 2, 3, 8):
+            spans = [shard_queries(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_bucket_single_process_is_a_scale():
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    GradBucket([p]).allreduce(0.5)
+    assert torch.equal(p.grad, torch.ones(3))
