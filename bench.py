@@ -228,6 +228,20 @@ def main():
         extra["fwd_loss_queries_per_s"] = round(world * args.steps * args.queries_per_step / (time.perf_counter() - tf0), 1)
         model.train()
 
+    # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/traffic_from_pmc.py)
+    traffic = {}
+    try:
+        import glob
+        tf = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+        if tf:
+            traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(tf[-1]))["kernels"].items()}
+    except Exception:
+        traffic = {}
+
+    def tr(key):
+        k = key.replace("gather_sum_kernel", "gather_sum_kernel<4>")
+        return traffic.get(k)
+
     # ---- per-kernel live timings (HIP events on the launch stream, timed region only)
     roof, roof_g, ktable = None, None, {}
     if records:
@@ -248,14 +262,14 @@ def main():
             n, secs, fl, by = mf[dom]
             ach = fl / secs / 1e12
             roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches=n,
+                        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=tr(dom), launches=n,
                         avg_launch_us=round(secs / n * 1e6, 2),
                         algorithmic_flops_per_launch=round(fl / n), algorithmic_bytes_per_launch=round(by / n))
         if "gather_sum_kernel" in agg:
             n, secs, fl, by = agg["gather_sum_kernel"]
             ach = by / secs / 1e9
             roof_g = dict(kernel="gather_sum_kernel", bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS,
-                          unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, launches=n,
+                          unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), traffic=tr("gather_sum_kernel"), launches=n,
                           avg_launch_us=round(secs / n * 1e6, 2), algorithmic_bytes_per_launch=round(by / n))
 
     cpu = None

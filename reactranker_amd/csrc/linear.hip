@@ -470,9 +470,16 @@ __global__ void __launch_bounds__(THREADS) wgrad_kernel(const WgradParams P) {
   __shared__ __attribute__((aligned(16))) float lds[2][2 * WMT * WLD];
   const rr_wgrad_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bn = blockIdx.x / P.nblk_k, bk = blockIdx.x % P.nblk_k;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so the
+  // nblk_n * nblk_k output tiles of ONE M-chunk get consecutive slots of one XCD: the second reader
+  // of every dZ / X row hits that XCD's L2 instead of HBM (speed only; any placement is correct).
+  const int nt = P.nblk_n * P.nblk_k;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = slot % nt, chunk = (slot / nt) * 8 + xcd;
+  if (chunk >= P.nchunks) return;
+  const int bn = tile / P.nblk_k, bk = tile % P.nblk_k;
   const int nb = bn * WBN, kb = bk * WBN;
-  const int64_t mbeg = static_cast<int64_t>(blockIdx.y) * P.rows_per_chunk;
+  const int64_t mbeg = static_cast<int64_t>(chunk) * P.rows_per_chunk;
   int64_t mend = mbeg + P.rows_per_chunk;
   if (mend > a.M) mend = a.M;
   const int flags = P.flags;
@@ -583,7 +590,7 @@ __global__ void __launch_bounds__(THREADS) wgrad_kernel(const WgradParams P) {
   }
 
   // partial slab [chunk][ N*K (dw, row-major) | N (dbias) ]; D[i = n][j = k]: lane -> n = .. + fq*4 + e, k = .. + fr
-  float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(blockIdx.y) * P.slab;
+  float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(chunk) * P.slab;
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
 #pragma unroll
@@ -620,9 +627,16 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   __shared__ __attribute__((aligned(16))) float lds[2][2 * WMT * WLD];
   const rr_wgrad_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bn = blockIdx.x / P.nblk_k, bk = blockIdx.x % P.nblk_k;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so the
+  // nblk_n * nblk_k output tiles of ONE M-chunk get consecutive slots of one XCD: the second reader
+  // of every dZ / X row hits that XCD's L2 instead of HBM (speed only; any placement is correct).
+  const int nt = P.nblk_n * P.nblk_k;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = slot % nt, chunk = (slot / nt) * 8 + xcd;
+  if (chunk >= P.nchunks) return;
+  const int bn = tile / P.nblk_k, bk = tile % P.nblk_k;
   const int nb = bn * WBN, kb = bk * WBN;
-  const int64_t mbeg = static_cast<int64_t>(blockIdx.y) * P.rows_per_chunk;
+  const int64_t mbeg = static_cast<int64_t>(chunk) * P.rows_per_chunk;
   int64_t mend = mbeg + P.rows_per_chunk;
   if (mend > a.M) mend = a.M;
   const int K = a.k1 + a.k2;
@@ -757,7 +771,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
     __syncthreads();
   }
 
-  float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(blockIdx.y) * P.slab;
+  float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(chunk) * P.slab;
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
 #pragma unroll
@@ -949,7 +963,7 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
   if (a.mask && vec_ok(a.mask, a.ld_mask)) P.flags |= F_MASK_VEC;
   if (vec_ok(a.dy, a.ld_dy)) P.flags |= F_EPI_VEC;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  dim3 grid(static_cast<unsigned>(P.nblk_n * P.nblk_k), static_cast<unsigned>(P.nchunks));
+  dim3 grid(static_cast<unsigned>(P.nblk_n * P.nblk_k * ((P.nchunks + 7) / 8) * 8));
   bool fast = (P.flags & F_EPI_VEC) != 0;
   if (a.mask && !(P.flags & F_MASK_VEC)) fast = false;
   if (a.k1 > 0 && !(P.flags & F_A1_VEC)) fast = false;

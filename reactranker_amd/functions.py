@@ -172,7 +172,9 @@ def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=N
     A.dbias = ptr(dbias)
     A.accumulate = int(accumulate)
     A.workspace, A.workspace_bytes = ptr(ws), nbytes
-    with _Timed("wgrad_kernel", 2 * M * N * (K + 1), 4 * (M * N * (2 if mask is not None else 1) + M * K + N * K)):
+    # the event pair spans the main kernel and its ~12 us fixed-order reduce kernel
+    key = f"wgrad_fast_kernel<{'true' if mask is not None else 'false'},{'true' if x1_sub is not None else 'false'}>"
+    with _Timed(key, 2 * M * N * (K + 1), 4 * (M * N * (2 if mask is not None else 1) + M * K + N * K)):
         check(lib().rr_linear_wgrad_f32(C.byref(A), stream()), "rr_linear_wgrad_f32")
     return dw
 
