@@ -155,9 +155,50 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     return out
 
 
+class SideStream:
+    """Weight-gradient GEMMs are off the backward critical path (nothing downstream reads dW until the
+    optimizer), so they run on a second HIP stream next to the dX / gather chain: their workgroups fill
+    the tail rounds and the prologue/epilogue bubbles of the main stream's kernels.
+    Ordering: the side stream waits for the main stream before each launch (inputs ready); every input
+    tensor is record_stream()-ed so the caching allocator does not recycle it early; join() makes the
+    main stream wait for all outstanding weight gradients."""
+    enabled = True
+    _streams = {}
+
+    @classmethod
+    def get(cls, device):
+        key = str(device)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=device)
+        return cls._streams[key]
+
+    @classmethod
+    def join(cls, device):
+        if cls.enabled and str(device) in cls._streams:
+            torch.cuda.current_stream(device).wait_stream(cls._streams[str(device)])
+
+
 def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=None, k1=0, x1_idx=None, x1_sub=None,
-          x1_sub_idx=None, x2=None, k2=0, accumulate=False, ld_dw=None):
-    """dw (+)= dZ^T [X1|X2], dbias (+)= colsum(dZ) with dZ = dy * (mask > 0) * mask_scale."""
+          x1_sub_idx=None, x2=None, k2=0, accumulate=False, ld_dw=None, side=False):
+    """dw (+)= dZ^T [X1|X2], dbias (+)= colsum(dZ) with dZ = dy * (mask > 0) * mask_scale.
+    side=True (the model's backward passes) launches on the weight-gradient stream; the caller must
+    SideStream.join() before anything reads dw/dbias."""
+    if side and SideStream.enabled:
+        main = torch.cuda.current_stream(dy.device)
+        side = SideStream.get(dy.device)
+        if side != main:
+            side.wait_stream(main)
+            for t in (dy, mask, x1, x1_idx, x1_sub, x1_sub_idx, x2, dw, dbias):
+                if t is not None:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                return _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub, x1_sub_idx, x2, k2,
+                                     accumulate, ld_dw)
+    return _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub, x1_sub_idx, x2, k2, accumulate,
+                         ld_dw)
+
+
+def _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub, x1_sub_idx, x2, k2, accumulate, ld_dw):
     K = k1 + k2
     nbytes = lib().rr_linear_wgrad_workspace_bytes(M, N, K)
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dy.device)
@@ -308,7 +349,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
     gWo, gbo = Wo.grads()
     gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
     # atom_hiddens = drop(relu([f_atoms | a_last] W_o^T + b_o))
-    wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H)
+    wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
     d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
     # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)]
     d_msg = gather_sum(d_a, g.b2t, H)
@@ -323,7 +364,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
             if first:
                 d_inp = torch.empty_like(d_msg)
             wgrad(nB, H, d_msg, gWh, dbias=gbh, mask=msgs[it + 1], mask_scale=ks, x1=amsgs[it], k1=H, x1_idx=g.b2a,
-                  x1_sub=msgs[it], x1_sub_idx=g.b2revb, accumulate=(it != depth - 2))
+                  x1_sub=msgs[it], x1_sub_idx=g.b2revb, accumulate=(it != depth - 2), side=True)
             d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
                            dz_out=d_inp, dz_accumulate=not first)    # d_inp (+)= dZ on the way through
         else:
@@ -332,17 +373,17 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
             if first:
                 d_inp = dz
             wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it],
-                  x1_sub_idx=g.b2revb, accumulate=(it != depth - 2))
+                  x1_sub_idx=g.b2revb, accumulate=(it != depth - 2), side=True)
             d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
         d_a = gather_sum(d_min, g.a2b_rev_t, H)                     # sum over the atom's outgoing bonds
-        d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H, out=d_msg)
+        d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H)          # fresh buffer: the side stream may still read the old one
         _pad_row_fix(d_msg, d_a, g, H)
     # msgs[0] = relu(inp)
     if d_inp is None:
         d_inp = relu_bwd(d_msg, msgs[0], 1.0)
     else:
         relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
-    wgrad(nB, H, d_inp, gWi, dbias=gbi, x1=g.f_bonds, k1=FBOND)
+    wgrad(nB, H, d_inp, gWi, dbias=gbi, x1=g.f_bonds, k1=FBOND, side=True)
     return gWi, gbi, gWh, gbh, gWo, gbo
 
 
@@ -390,7 +431,7 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
     d_hid = segment_mean_bwd(dvecs, g, H, F, out_drop_p, out_seed)                        # [nA,H]
     d_x = None
     if depth > 0:
-        wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x2=a_last, k2=H)
+        wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x2=a_last, k2=H, side=True)
         # dX over both column segments of W_o: [d_x | d_a]
         d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
         d_a = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
@@ -405,7 +446,7 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
                 if first:
                     d_inp = torch.empty_like(d_msg)
                 wgrad(nA, H, d_msg, gWh, dbias=gbh, mask=msgs[it + 1], mask_scale=ks, x1=amsgs[it], k1=H, x2=fb,
-                      k2=FBOND, accumulate=(it != depth - 2))
+                      k2=FBOND, accumulate=(it != depth - 2), side=True)
                 d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
                              dz_out=d_inp, dz_accumulate=not first)
             else:
@@ -413,9 +454,9 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
                 dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
                 if first:
                     d_inp = dz
-                wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2))
+                wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2), side=True)
                 d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
-            d_msg = gather_sum(d_a, g.a2a_t, H, out=d_msg)
+            d_msg = gather_sum(d_a, g.a2a_t, H)                     # fresh buffer (side-stream readers)
             _pad_row_fix(d_msg, d_a, g, H)
         if d_inp is None:
             d_inp = relu_bwd(d_msg, msgs[0], 1.0)
@@ -423,7 +464,7 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
             relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
     else:
         d_inp = relu_bwd(d_hid, msgs[0], ks)                        # hid = drop(relu(inp))
-    wgrad(nA, H, d_inp, gWi, dbias=gbi, x1=x, k1=Hin, x1_sub=x_sub)
+    wgrad(nA, H, d_inp, gWi, dbias=gbi, x1=x, k1=Hin, x1_sub=x_sub, side=True)
     if d_x is None:
         d_x = linear(nA, Hin, Wi.pk_t(0, Hin), w_packed=True, a1=d_inp, k1=H)
     else:
@@ -453,7 +494,7 @@ def ffn_backward(layers: List[LinW], p: float, head: int, saved, dout, need_dx: 
     d = dout if head == 0 else head_bwd(dout, raw, head)
     L = layers[-1]
     gw, gb = L.grads()
-    wgrad(M, L.w.shape[0], d, gw, dbias=gb, x1=hs[-1], k1=L.w.shape[1])
+    wgrad(M, L.w.shape[0], d, gw, dbias=gb, x1=hs[-1], k1=L.w.shape[1], side=True)
     grads.append((gw, gb))
     dx = None
     if len(layers) > 1 or need_dx:
@@ -462,7 +503,7 @@ def ffn_backward(layers: List[LinW], p: float, head: int, saved, dout, need_dx: 
         L = layers[li]
         gw, gb = L.grads()
         y = hs[li + 1]                                              # drop(relu(.)) output of this layer
-        wgrad(M, L.w.shape[0], dx, gw, dbias=gb, mask=y, mask_scale=ks, x1=hs[li], k1=L.w.shape[1])
+        wgrad(M, L.w.shape[0], dx, gw, dbias=gb, mask=y, mask_scale=ks, x1=hs[li], k1=L.w.shape[1], side=True)
         grads.append((gw, gb))
         if li > 0 or need_dx:
             dx = linear(M, L.w.shape[1], L.pk_t(0, L.w.shape[1]), w_packed=True, a1=dx, k1=L.w.shape[0], a_mask=y, mask_scale=ks)
@@ -542,6 +583,7 @@ class ReactionModelFn(torch.autograd.Function):
                                                                  _site_seed(seed, 4))
         gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
         gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_diff, -1.0)
+        SideStream.join(dout.device)                                # weight gradients are complete from here on
         genc = []
         for a, b in zip(gp, gr):                                    # the two encoder passes share weights
             genc.append(None if a is None else axpby(1.0, a, 1.0, b, out=a))
@@ -550,6 +592,7 @@ class ReactionModelFn(torch.autograd.Function):
             grads += [gw, gb]
         grads = [gq if present else None for gq, present in zip(grads, ctx.present)]
         ctx.saved = None
+        SideStream.join(dout.device)
         return (None, *grads)
 
 
@@ -569,6 +612,7 @@ class MPNFn(torch.autograd.Function):
         st, m = ctx.st, ctx.mods
         g = mpn_backward(st["g"], st["H"], st["depth"], m[0], m[1], m[2], st["p"], ctx.saved,
                          _rowmajor(dh, "grad"), 1.0)
+        SideStream.join(dh.device)
         return (None, *[gq if pr else None for gq, pr in zip(g, ctx.present)])
 
 
@@ -590,6 +634,7 @@ class MPNDiffFn(torch.autograd.Function):
         st, m = ctx.st, ctx.mods
         res = mpndiff_backward(st["g"], st["H"], st["depth"], m[0], m[1], m[2], st["p"], ctx.saved, ctx.x, None,
                                _rowmajor(dvecs, "grad"), st["F"], 0.0, 0)
+        SideStream.join(dvecs.device)
         return (None, res[0], *[gq if pr else None for gq, pr in zip(res[1:], ctx.present)])
 
 
@@ -619,4 +664,5 @@ class FFNFn(torch.autograd.Function):
         grads = []
         for gw, gb in fg:
             grads += [gw, gb]
+        SideStream.join(dout.device)
         return (None, dx, *[gq if pr else None for gq, pr in zip(grads, ctx.present)])

@@ -307,3 +307,75 @@ def test_full_step_size_properties():
     ref = O.reaction_forward(O.params_from_numpy(w), dict(depth=3, diff_depth=3, ffn_depth=3, task_type="with_softplus"),
                              O.pack_batch(qb.r_specs[sl], K=4), O.pack_batch(qb.p_specs[sl], K=4), qb.add_features[sl])
     close(out1[sl], ref, what="oracle spot check")
+
+
+@pytest.mark.parametrize("name,cfg,scope,loss_kind", [
+    ("cfg2_listnet_h300_c32", dict(hidden_size=300, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True,
+                                   task_num=1, ffn_last_layer="with_softplus", task_type=None, add_features_dim=1),
+     [32, 32, 32], "listnet"),
+    ("cfg4_ranknet_h300_c64", dict(hidden_size=300, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True,
+                                   task_num=1, ffn_last_layer="no_softplus", task_type=None, add_features_dim=1),
+     [64, 64], "ranknet"),
+    ("cfg5_evidential_h600_d6", dict(hidden_size=600, mpnn_depth=6, mpnn_diff_depth=6, ffn_depth=3, use_bias=True,
+                                     task_num=2, ffn_last_layer="no_softplus", task_type="evidential_ranking",
+                                     add_features_dim=1), [9, 16, 5], "evidential"),
+])
+def test_baseline_configs_against_oracle(name, cfg, scope, loss_kind):
+    """The other BASELINE.json configurations (ListNet 32-candidate lists; RankNet over 64-candidate lists;
+    UC-Listwise with hidden 600 / depth 6) at oracle-sized batches: scores, loss and every gradient."""
+    H = cfg["hidden_size"]
+    shapes = O.model_shapes(H, cfg["mpnn_depth"], cfg["mpnn_diff_depth"], cfg["ffn_depth"], cfg["task_num"],
+                            cfg["add_features_dim"], cfg["use_bias"])
+    w = synth.seeded_weights(shapes, 31)
+    model = make_model(cfg, w).eval()
+    head = O.resolve_task_type(cfg["task_num"], cfg["ffn_last_layer"], cfg["task_type"])
+    qb = synth.make_queries(41, len(scope), scope, atoms_lo=6, atoms_hi=14)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    targets = torch.tensor(qb.targets)
+    P = O.params_from_numpy(w, requires_grad=True)
+    mc = dict(depth=cfg["mpnn_depth"], diff_depth=cfg["mpnn_diff_depth"], ffn_depth=cfg["ffn_depth"], task_type=head)
+    ref = O.reaction_forward(P, mc, O.pack_batch(qb.r_specs, K=4), O.pack_batch(qb.p_specs, K=4), qb.add_features)
+    out = model(rb, pb, gpu=0, add_features=qb.add_features)
+    close(out, ref, tol=2e-5 if H == 600 else 1e-5, what=name + " out")
+    if loss_kind == "listnet":
+        l, l_ref = RL.ListnetLoss()(out, scope, targets, 0), O.listnet_loss(ref, scope, targets)
+    elif loss_kind == "evidential":
+        l, l_ref = RL.evidential_ranking()(out, scope, targets, None, None, None, 0), \
+            O.evidential_ranking_loss(ref, scope, targets)
+    else:
+        ls, pairs = RL.ranknet_loss(out, scope, targets, 1.0, 0)
+        ls_ref, pairs_ref = O.ranknet_sum_session(ref, scope, targets, 1.0)
+        assert int(pairs) == int(pairs_ref)
+        l, l_ref = ls / pairs, ls_ref / pairs_ref
+    close(l.reshape(-1), l_ref.reshape(-1), tol=2e-5, what=name + " loss")
+    names = [k for k in P if P[k].requires_grad]
+    g_ref = torch.autograd.grad(l_ref.sum(), [P[k] for k in names], allow_unused=True)
+    # fp64 run of the same oracle = ground truth; the fp32 oracle's own distance to it is the noise floor
+    P64 = {k: v.detach().double().requires_grad_(v.requires_grad) for k, v in P.items()}
+
+    def g64(specs):
+        g = O.graph_tensors(O.pack_batch(specs, K=4))
+        g["f_atoms"], g["f_bonds"] = g["f_atoms"].double(), g["f_bonds"].double()
+        return g
+    ref64 = O.reaction_forward(P64, mc, g64(qb.r_specs), g64(qb.p_specs), torch.tensor(qb.add_features).double())
+    t64 = targets.double()
+    if loss_kind == "listnet":
+        l64 = O.listnet_loss(ref64, scope, t64)
+    elif loss_kind == "evidential":
+        l64 = O.evidential_ranking_loss(ref64, scope, t64)
+    else:
+        ls64, p64 = O.ranknet_sum_session(ref64, scope, t64, 1.0)
+        l64 = ls64 / p64
+    g_64 = torch.autograd.grad(l64.sum(), [P64[k] for k in names], allow_unused=True)
+    model.zero_grad()
+    l.sum().backward()
+    got = dict(model.named_parameters())
+    for k, gr, gd in zip(names, g_ref, g_64):
+        gr = torch.zeros_like(P[k]) if gr is None else gr
+        gd = torch.zeros_like(P64[k]) if gd is None else gd
+        g = got[k].grad
+        g = torch.zeros_like(got[k]) if g is None else g
+        err = float((g.detach().cpu().double() - gd).abs().max())
+        noise = float((gr.double() - gd).abs().max())                 # what fp32 on the CPU loses on this tensor
+        bound = max(5e-5 * float(gd.abs().max()) + 1e-6, 3.0 * noise)
+        assert err <= bound, f"{name} grad {k}: |err vs fp64| {err:.3e} > {bound:.3e} (fp32 oracle noise {noise:.3e})"
