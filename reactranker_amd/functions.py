@@ -178,6 +178,22 @@ class SideStream:
             torch.cuda.current_stream(device).wait_stream(cls._streams[str(device)])
 
 
+class AuxStream:
+    """Second compute stream for the reactant encoder: encoder(r) and encoder(p) are independent
+    (models/base_model.py:155-156), so their kernel chains run concurrently and fill each other's
+    tail rounds.  Used by ReactionModelFn only."""
+    enabled = True
+    backward = False        # measured: concurrent r/p backward chains cost ~2 % (they fight the weight-gradient stream)
+    _streams = {}
+
+    @classmethod
+    def get(cls, device):
+        key = str(device)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=device)
+        return cls._streams[key]
+
+
 def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=None, k1=0, x1_idx=None, x1_sub=None,
           x1_sub_idx=None, x2=None, k2=0, accumulate=False, ld_dw=None, side=False):
     """dw (+)= dZ^T [X1|X2], dbias (+)= colsum(dZ) with dZ = dy * (mask > 0) * mask_scale.
@@ -556,8 +572,23 @@ class ReactionModelFn(torch.autograd.Function):
         ffn = [LinW(params[i], params[i + 1]) for i in range(12, len(params), 2)]
         H, p, seed = st["H"], st["p"], st["seed"]
         rg, pg = st["r"], st["p_graph"]
-        r_h, r_saved = mpn_forward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
-        p_h, p_saved = mpn_forward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 2))
+        dev = rg.f_bonds.device
+        main = torch.cuda.current_stream(dev)
+        if AuxStream.enabled:
+            enc[0].pk(FBOND)                                        # shared packed weights: build once, on main
+            if enc[1] is not None:
+                enc[1].pk(H)
+            enc[2].pk(ATOM_FDIM, H)
+            aux = AuxStream.get(dev)
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                r_h, r_saved = mpn_forward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
+            p_h, p_saved = mpn_forward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 2))
+            main.wait_stream(aux)
+            r_h.record_stream(main)
+        else:
+            r_h, r_saved = mpn_forward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
+            p_h, p_saved = mpn_forward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 2))
         vecs, d_saved = mpndiff_forward(pg, H, st["diff_depth"], dif[0], dif[1], dif[2], p, _site_seed(seed, 3),
                                         p_h, r_h, st["feat"], st["F"], out_drop_p=p, out_seed=_site_seed(seed, 4))
         out, f_saved = ffn_forward(vecs, ffn, p, _site_seed(seed, 5), st["head"])
@@ -581,8 +612,25 @@ class ReactionModelFn(torch.autograd.Function):
         d_diff, gWi, gbi, gWh, gbh, gWo, gbo = mpndiff_backward(pg, H, st["diff_depth"], dif[0], dif[1], dif[2], p,
                                                                  d_saved, p_h, r_h, dvecs, st["F"], p,
                                                                  _site_seed(seed, 4))
-        gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
-        gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_diff, -1.0)
+        if AuxStream.enabled and AuxStream.backward:
+            dev = dout.device
+            main = torch.cuda.current_stream(dev)
+            aux = AuxStream.get(dev)
+            if enc[1] is not None:
+                enc[1].pk_t(0, H)                                   # shared packed transposes: build once, on main
+            enc[2].pk_t(ATOM_FDIM, ATOM_FDIM + H)
+            aux.wait_stream(main)
+            d_diff.record_stream(aux)
+            with torch.cuda.stream(aux):
+                gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_diff, -1.0)
+            gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
+            main.wait_stream(aux)
+            for t in gr:
+                if t is not None:
+                    t.record_stream(main)
+        else:
+            gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
+            gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_diff, -1.0)
         SideStream.join(dout.device)                                # weight gradients are complete from here on
         genc = []
         for a, b in zip(gp, gr):                                    # the two encoder passes share weights
