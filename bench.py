@@ -152,11 +152,14 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("RR_SINGLE_DEVICE"):                # rehearsal of the N>1 path on a one-GPU box
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm (xGMI underneath); RR_DIST_BACKEND=gloo only for one-GPU rehearsals
+        dist.init_process_group(os.environ.get("RR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from reactranker_amd import functions as Fn
     from reactranker_amd import loss as RL
