@@ -83,6 +83,11 @@ class ReactionModel(nn.Module):
         if mpnn_hidden_size != mpnn_diff_hidden_size:
             raise NotImplementedError("build_model always ties the hidden sizes (reference base_model.py:266-280)")
         self.dropout_seed = None     # set to an int to pin the dropout streams (tests)
+        # Reactant de-duplication: every candidate of a query repeats the same reactant
+        # graph, so encoder(r) can run once per distinct reactant.  "auto": only when dropout is inactive
+        # (eval mode or p == 0), where it is exact; True: always (train-mode dropout then shares one mask per
+        # distinct reactant instead of one per copy — NOT the reference's sampling); False: never.
+        self.dedup_reactants = "auto"
 
     def flat_params(self):
         e, d = self.encoder, self.diff_encoder
@@ -93,6 +98,17 @@ class ReactionModel(nn.Module):
     def forward(self, r_inputs, p_inputs, gpu: int = None, add_features: List[np.ndarray] = None):
         rg = device_graph_of(r_inputs, gpu)
         pg = device_graph_of(p_inputs, gpu)
+        dedup = None
+        p_active = float(self.encoder.dropout) if self.training else 0.0
+        want = self.dedup_reactants is True or (self.dedup_reactants == "auto" and p_active == 0.0)
+        if want and hasattr(r_inputs, "unique"):
+            ub, amap, amap_t = r_inputs.unique()
+            if ub.n_mols < r_inputs.n_mols:
+                cache = getattr(r_inputs, "_rr_dedup_dev", None)
+                if cache is None or cache[0] != str(pg.device):
+                    cache = (str(pg.device), torch.from_numpy(amap).to(pg.device), torch.from_numpy(amap_t).to(pg.device))
+                    r_inputs._rr_dedup_dev = cache
+                dedup = (ub.device_graph(pg.device), cache[1], cache[2])
         if rg.nA != pg.nA:
             raise RuntimeError("reactant and product batches must hold the same atoms in the same order "
                                "(diff = p_h - r_h, reference models/base_model.py:168)")
@@ -114,7 +130,7 @@ class ReactionModel(nn.Module):
         seed = 0
         if p > 0:
             seed = _fresh_seed() if self.dropout_seed is None else int(self.dropout_seed)
-        st = dict(r=rg, p_graph=pg, H=self.encoder.hidden_size, depth=self.encoder.depth,
+        st = dict(r=rg if dedup is None else dedup[0], dedup=dedup, p_graph=pg, H=self.encoder.hidden_size, depth=self.encoder.depth,
                   diff_depth=self.diff_encoder.depth, p=p, seed=seed, feat=feat, F=F, head=self.ffn.head(),
                   squeeze=(self.ffn.task_num == 1))
         out = Fn.ReactionModelFn.apply(st, *self.flat_params())

@@ -199,6 +199,7 @@ class BatchMolGraph:
         self.atom_fdim = get_atom_fdim()
         self.bond_fdim = get_bond_fdim() + self.atom_fdim
         specs = [g.spec if isinstance(g, MolGraph) else g for g in graphs]
+        self._specs = specs                      # kept for unique(): repeated molecule objects are de-duplicated by identity
         if all(isinstance(s, MolSpec) for s in specs):
             arrs = _concat_specs(specs)
         else:
@@ -240,6 +241,48 @@ class BatchMolGraph:
 
     def get_components(self):
         return self.f_atoms, self.f_bonds, self.a2b, self.b2a, self.b2revb, self.a_scope, self.b_scope
+
+    def unique(self):
+        """De-duplicated view of the batch: (BatchMolGraph of the distinct molecule objects, atom map).
+
+        Every candidate of a query repeats the SAME reactant object (reference train_listwise.py:188 ->
+        load_reactions.py:574-577), so encoder(r) does C-fold redundant work.
+        `unique()` packs each distinct object once (same pad width K, so hazard H1 is unaffected) and returns
+        `amap` [nA] int32 (full-batch atom row -> row in the unique batch, row 0 -> 0) and its transpose
+        `amap_t` [nA_unique, C] (-1 padded) for the backward segment sum.  Identity-based: two equal molecules
+        built as different objects are not merged."""
+        if getattr(self, "_unique", None) is not None:
+            return self._unique
+        first, uidx = {}, []
+        for s in self._specs:
+            k = id(s)
+            if k not in first:
+                first[k] = len(first)
+            uidx.append(first[k])
+        useq = [None] * len(first)
+        for s, u in zip(self._specs, uidx):
+            useq[u] = s
+        ub = BatchMolGraph(useq, K=self.max_num_bonds) if len(useq) else BatchMolGraph([], K=None)
+        if ub.max_num_bonds != self.max_num_bonds:
+            raise RuntimeError("unique(): pad width mismatch")
+        h, hu = self._host, ub._host
+        nA = h["nA"]
+        amap = np.zeros(nA, np.int32)
+        uidx = np.asarray(uidx, np.int64)
+        if len(uidx):
+            start, size = h["a_scope"][:, 0].astype(np.int64), h["a_scope"][:, 1].astype(np.int64)
+            ustart = hu["a_scope"][uidx, 0].astype(np.int64)
+            rep = np.repeat(np.arange(len(uidx)), size)
+            within = np.arange(int(size.sum())) - np.repeat(np.cumsum(size) - size, size)
+            amap[start[rep] + within] = (ustart[rep] + within).astype(np.int32)
+        counts = np.bincount(amap, minlength=hu["nA"])
+        cmax = int(max(1, counts.max()))
+        amap_t = np.full((hu["nA"], cmax), -1, np.int32)
+        order = np.argsort(amap, kind="stable")
+        pos = np.arange(nA) - np.repeat(np.cumsum(counts) - counts, counts)
+        amap_t[amap[order], pos] = order.astype(np.int32)
+        self._unique = (ub, amap, amap_t)
+        return self._unique
 
     def get_a2a(self):
         return self.a2a

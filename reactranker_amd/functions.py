@@ -404,7 +404,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
 
 
 def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Optional[LinW], p: float, seed: int,
-                    x, x_sub=None, feat=None, F: int = 0, out_drop_p: float = 0.0, out_seed: int = 0):
+                    x, x_sub=None, feat=None, F: int = 0, out_drop_p: float = 0.0, out_seed: int = 0, x_sub_idx=None):
     """MPNDiff.forward (models/mpn.py:170-240).  atom_features = x - x_sub (x_sub=None: x itself);
     returns ([M, H+F] readout (+ optional FFN-input dropout), saved)."""
     nA = g.nA
@@ -412,7 +412,8 @@ def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Opt
     inp = _new(x, nA, H)
     msg = _new(x, nA, H)
     first_p = p if depth == 0 else 0.0                                                   # :221 (depth 0: dropout(message))
-    linear(nA, H, Wi.pk(Hin), w_packed=True, a1=x, k1=Hin, a1_sub=x_sub, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp,
+    linear(nA, H, Wi.pk(Hin), w_packed=True, a1=x, k1=Hin, a1_sub=x_sub, a1_sub_idx=x_sub_idx, bias=Wi.b, act=ACT_RELU,
+           out=msg, c_pre=inp,
            drop_p=first_p, seed=_site_seed(seed, 2000))                                  # :194-195
     msgs, amsgs = [msg], []
     a_last = None
@@ -425,7 +426,8 @@ def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Opt
             amsgs.append(a_msg)
             msgs.append(new)
         a_last = gather_sum(msgs[-1], g.a2a, H)                                          # :215-216
-        hid = linear(nA, H, Wo.pk(Hin, H), w_packed=True, a1=x, k1=Hin, a1_sub=x_sub, a2=a_last, k2=H, bias=Wo.b, act=ACT_RELU, drop_p=p,
+        hid = linear(nA, H, Wo.pk(Hin, H), w_packed=True, a1=x, k1=Hin, a1_sub=x_sub, a1_sub_idx=x_sub_idx, a2=a_last, k2=H,
+                     bias=Wo.b, act=ACT_RELU, drop_p=p,
                      seed=_site_seed(seed, 3000))                                        # :217-219
     else:
         hid = msg
@@ -435,7 +437,7 @@ def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Opt
 
 
 def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x, x_sub, dvecs, F: int,
-                     out_drop_p: float, out_seed: int):
+                     out_drop_p: float, out_seed: int, x_sub_idx=None):
     """Adjoint of mpndiff_forward -> (d_x [nA,Hin], gWi, gbi, gWh, gbh, gWo, gbo)."""
     msgs, amsgs, a_last, hid = saved
     nA = g.nA
@@ -447,7 +449,8 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
     d_hid = segment_mean_bwd(dvecs, g, H, F, out_drop_p, out_seed)                        # [nA,H]
     d_x = None
     if depth > 0:
-        wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x2=a_last, k2=H, side=True)
+        wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx,
+              x2=a_last, k2=H, side=True)
         # dX over both column segments of W_o: [d_x | d_a]
         d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
         d_a = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
@@ -480,7 +483,7 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
             relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
     else:
         d_inp = relu_bwd(d_hid, msgs[0], ks)                        # hid = drop(relu(inp))
-    wgrad(nA, H, d_inp, gWi, dbias=gbi, x1=x, k1=Hin, x1_sub=x_sub, side=True)
+    wgrad(nA, H, d_inp, gWi, dbias=gbi, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx, side=True)
     if d_x is None:
         d_x = linear(nA, Hin, Wi.pk_t(0, Hin), w_packed=True, a1=d_inp, k1=H)
     else:
@@ -589,8 +592,10 @@ class ReactionModelFn(torch.autograd.Function):
         else:
             r_h, r_saved = mpn_forward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
             p_h, p_saved = mpn_forward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 2))
+        dd = st.get("dedup")                                         # (unique reactant graph, amap, amap_t) or None
         vecs, d_saved = mpndiff_forward(pg, H, st["diff_depth"], dif[0], dif[1], dif[2], p, _site_seed(seed, 3),
-                                        p_h, r_h, st["feat"], st["F"], out_drop_p=p, out_seed=_site_seed(seed, 4))
+                                        p_h, r_h, st["feat"], st["F"], out_drop_p=p, out_seed=_site_seed(seed, 4),
+                                        x_sub_idx=None if dd is None else dd[1])
         out, f_saved = ffn_forward(vecs, ffn, p, _site_seed(seed, 5), st["head"])
         ctx.st, ctx.mods = st, (enc, dif, ffn)
         ctx.saved = (r_saved, p_saved, d_saved, f_saved, r_h, p_h)
@@ -609,9 +614,13 @@ class ReactionModelFn(torch.autograd.Function):
         rg, pg = st["r"], st["p_graph"]
         dout = _rowmajor(dout.reshape(f_saved[1].shape), "grad_output")
         dvecs, fg = ffn_backward(ffn, p, st["head"], f_saved, dout, need_dx=True)
+        dd = st.get("dedup")
         d_diff, gWi, gbi, gWh, gbh, gWo, gbo = mpndiff_backward(pg, H, st["diff_depth"], dif[0], dif[1], dif[2], p,
                                                                  d_saved, p_h, r_h, dvecs, st["F"], p,
-                                                                 _site_seed(seed, 4))
+                                                                 _site_seed(seed, 4),
+                                                                 x_sub_idx=None if dd is None else dd[1])
+        # de-duplicated reactants: d r_h[u] = -(sum over the copies of atom u of d_diff) (fixed-order segment sum)
+        d_r = d_diff if dd is None else gather_sum(d_diff, dd[2], H)
         if AuxStream.enabled and AuxStream.backward:
             dev = dout.device
             main = torch.cuda.current_stream(dev)
@@ -620,9 +629,9 @@ class ReactionModelFn(torch.autograd.Function):
                 enc[1].pk_t(0, H)                                   # shared packed transposes: build once, on main
             enc[2].pk_t(ATOM_FDIM, ATOM_FDIM + H)
             aux.wait_stream(main)
-            d_diff.record_stream(aux)
+            d_r.record_stream(aux)
             with torch.cuda.stream(aux):
-                gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_diff, -1.0)
+                gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0)
             gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
             main.wait_stream(aux)
             for t in gr:
@@ -630,7 +639,7 @@ class ReactionModelFn(torch.autograd.Function):
                     t.record_stream(main)
         else:
             gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
-            gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_diff, -1.0)
+            gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0)
         SideStream.join(dout.device)                                # weight gradients are complete from here on
         genc = []
         for a, b in zip(gp, gr):                                    # the two encoder passes share weights

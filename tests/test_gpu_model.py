@@ -379,3 +379,39 @@ def test_baseline_configs_against_oracle(name, cfg, scope, loss_kind):
         noise = float((gr.double() - gd).abs().max())                 # what fp32 on the CPU loses on this tensor
         bound = max(5e-5 * float(gd.abs().max()) + 1e-6, 3.0 * noise)
         assert err <= bound, f"{name} grad {k}: |err vs fp64| {err:.3e} > {bound:.3e} (fp32 oracle noise {noise:.3e})"
+
+
+def test_reactant_dedup_is_exact_without_dropout(golden_dir):
+    """encoding each distinct reactant once (eval mode / p = 0) gives the same scores,
+    loss and gradients as encoding all C copies; with train-mode dropout 'auto' keeps the reference's
+    per-copy sampling (no de-duplication)."""
+    d, cfg = Hh.load_case(f"{golden_dir}/model_F_h300_d3_c64.npz")
+    shapes = O.model_shapes(300, 3, 3, 3, 1, 1, True)
+    w = Hh.case_weights(d, cfg, shapes)
+    qb = Hh.case_queries(cfg)
+    scope, targets = cfg["scope"], torch.tensor(d["targets"])
+    res = {}
+    for mode in (False, "auto"):
+        model = make_model(cfg, w).eval()
+        model.dedup_reactants = mode
+        rb, pb = featurization.BatchMolGraph(qb.r_specs), featurization.BatchMolGraph(qb.p_specs)
+        out = model(rb, pb, gpu=0, add_features=d["add_features"])
+        l = RL.MLEloss()(out, scope, targets, 0)
+        l.sum().backward()
+        res[mode] = (out.detach(), l.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    ub, amap, amap_t = featurization.BatchMolGraph(qb.r_specs).unique()
+    assert ub.n_mols == len(scope) and ub.n_mols < len(qb.r_specs)
+    close(res["auto"][0], d["out"], what="dedup vs reference vectors")
+    close(res["auto"][0], res[False][0], tol=2e-6, what="dedup vs full scores")
+    close(res["auto"][1], res[False][1], tol=2e-6, what="dedup vs full loss")
+    for k, g in res[False][2].items():
+        err = float((res["auto"][2][k] - g).abs().max())
+        assert err <= 2e-5 * float(g.abs().max()) + 1e-6, (k, err)
+    # train mode with dropout: 'auto' must NOT de-duplicate (the dropout stream stays per copy)
+    model = make_model(cfg, w, dropout=0.2).train()
+    model.dropout_seed = 7
+    rb, pb = featurization.BatchMolGraph(qb.r_specs), featurization.BatchMolGraph(qb.p_specs)
+    a = model(rb, pb, gpu=0, add_features=d["add_features"]).detach()
+    model.dedup_reactants = False
+    b = model(rb, pb, gpu=0, add_features=d["add_features"]).detach()
+    assert torch.equal(a, b)
