@@ -63,6 +63,12 @@ int rr_gather_diff_f32(const float* a, int64_t n_a, int64_t ld_a, const int32_t*
                        const float* m, int64_t n_m, int64_t ld_m, const int32_t* im,
                        int64_t n_out, int H, float* out, int64_t ld_out, rr_stream_t stream);
 
+/* out[r, c] = keep(seed, r*H + c) ? src[idx[r], c] / (1 - p) : 0     (idx[r] < 0 -> 0)
+ * Expands rows shared by several destinations and applies each destination's own dropout mask: the
+ * message after the first W_h of a de-duplicated reactant (same mask stream as rr_linear_f32's epilogue). */
+int rr_gather_dropout_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int H,
+                          float drop_p, uint64_t drop_seed, float* out, int64_t ld_out, rr_stream_t stream);
+
 /* out[0:H] (+)= sum_r w[r] * x[r, 0:H]   (w == NULL -> all ones).
  * Backward of the padding row: the reference gathers row 0 (K - deg(a)) times per atom
  * (features/featurization.py:286), so d_src[0] = sum_a npad[a] * d_out[a].  Also used for
@@ -111,6 +117,8 @@ typedef struct rr_linear_args {
   int w_packed;                                     /* 1: the zero-padded layout of rr_pack_weight_f32 */
   const float* bias;                                /* [N] or NULL */
   const float* residual; int64_t ldr;               /* [M, N] or NULL */
+  const int32_t* residual_idx;                      /* optional: row m adds residual[residual_idx[m]] (shared `input`
+                                                       of a de-duplicated reactant, models/mpn.py:95) */
   int act;                                          /* rr_act */
   float drop_p;          uint64_t drop_seed;        /* drop_p == 0 -> no dropout */
   float* c;              int64_t ldc;

@@ -32,7 +32,7 @@ class LinearArgs(C.Structure):
         ("dz_out", c_f32p), ("ld_dz", i64), ("dz_accumulate", i32),
         ("w", c_f32p), ("ldw", i64), ("w_packed", i32),
         ("bias", c_f32p),
-        ("residual", c_f32p), ("ldr", i64),
+        ("residual", c_f32p), ("ldr", i64), ("residual_idx", c_i32p),
         ("act", i32), ("drop_p", f32), ("drop_seed", u64),
         ("c", c_f32p), ("ldc", i64),
         ("c_pre", c_f32p), ("ld_pre", i64),
@@ -60,6 +60,7 @@ _SIGS = {
     "rr_abi_struct_sizes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rr_gather_sum_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, c_stream]),
     "rr_gather_diff_f32": (i32, [c_f32p, i64, i64, c_i32p, c_f32p, i64, i64, c_i32p, i64, i32, c_f32p, i64, c_stream]),
+    "rr_gather_dropout_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, f32, u64, c_f32p, i64, c_stream]),
     "rr_colsum_workspace_bytes": (C.c_size_t, [i64, i32]),
     "rr_weighted_colsum_f32": (i32, [c_f32p, i64, i64, c_f32p, i32, c_f32p, i32, C.c_void_p, C.c_size_t, c_stream]),
     "rr_linear_f32": (i32, [C.POINTER(LinearArgs), c_stream]),

@@ -84,9 +84,9 @@ class ReactionModel(nn.Module):
             raise NotImplementedError("build_model always ties the hidden sizes (reference base_model.py:266-280)")
         self.dropout_seed = None     # set to an int to pin the dropout streams (tests)
         # Reactant de-duplication: every candidate of a query repeats the same reactant
-        # graph, so encoder(r) can run once per distinct reactant.  "auto": only when dropout is inactive
-        # (eval mode or p == 0), where it is exact; True: always (train-mode dropout then shares one mask per
-        # distinct reactant instead of one per copy — NOT the reference's sampling); False: never.
+        # graph.  "auto" (default): with dropout inactive (eval or p == 0) encoder(r) runs once per distinct
+        # reactant; in train mode with dropout only its deterministic prefix (everything before the first
+        # dropout) is shared and each copy keeps its own mask stream.  Both are exact.  False: never share.
         self.dedup_reactants = "auto"
 
     def flat_params(self):
@@ -100,7 +100,7 @@ class ReactionModel(nn.Module):
         pg = device_graph_of(p_inputs, gpu)
         dedup = None
         p_active = float(self.encoder.dropout) if self.training else 0.0
-        want = self.dedup_reactants is True or (self.dedup_reactants == "auto" and p_active == 0.0)
+        want = self.dedup_reactants in ("auto", True) and p_active == 0.0
         if want and hasattr(r_inputs, "unique"):
             ub, amap, amap_t = r_inputs.unique()
             if ub.n_mols < r_inputs.n_mols:
@@ -109,6 +109,19 @@ class ReactionModel(nn.Module):
                     cache = (str(pg.device), torch.from_numpy(amap).to(pg.device), torch.from_numpy(amap_t).to(pg.device))
                     r_inputs._rr_dedup_dev = cache
                 dedup = (ub.device_graph(pg.device), cache[1], cache[2])
+        prefix = None
+        if (dedup is None and self.dedup_reactants in ("auto", True) and p_active > 0.0 and self.encoder.depth >= 2
+                and hasattr(r_inputs, "unique_bonds")):
+            # train mode with dropout: only the deterministic prefix of the reactant encoder (up to its first
+            # dropout) is shared across the copies — exact, the per-copy mask stream is unchanged
+            ub, _, _ = r_inputs.unique()
+            if ub.n_mols < r_inputs.n_mols:
+                cache = getattr(r_inputs, "_rr_prefix_dev", None)
+                if cache is None or cache[0] != str(pg.device):
+                    bmap, bmap_t = r_inputs.unique_bonds()
+                    cache = (str(pg.device), torch.from_numpy(bmap).to(pg.device), torch.from_numpy(bmap_t).to(pg.device))
+                    r_inputs._rr_prefix_dev = cache
+                prefix = (ub.device_graph(pg.device), cache[1], cache[2])
         if rg.nA != pg.nA:
             raise RuntimeError("reactant and product batches must hold the same atoms in the same order "
                                "(diff = p_h - r_h, reference models/base_model.py:168)")
@@ -130,7 +143,7 @@ class ReactionModel(nn.Module):
         seed = 0
         if p > 0:
             seed = _fresh_seed() if self.dropout_seed is None else int(self.dropout_seed)
-        st = dict(r=rg if dedup is None else dedup[0], dedup=dedup, p_graph=pg, H=self.encoder.hidden_size, depth=self.encoder.depth,
+        st = dict(r=rg if dedup is None else dedup[0], dedup=dedup, prefix=prefix, p_graph=pg, H=self.encoder.hidden_size, depth=self.encoder.depth,
                   diff_depth=self.diff_encoder.depth, p=p, seed=seed, feat=feat, F=F, head=self.ffn.head(),
                   squeeze=(self.ffn.task_num == 1))
         out = Fn.ReactionModelFn.apply(st, *self.flat_params())

@@ -74,6 +74,34 @@ __global__ void __launch_bounds__(256) gather_diff_kernel(const float* __restric
   }
 }
 
+// out[r] = dropout(src[idx[r]]) with the destination row's own mask (index r*H + c)
+template <int VEC>
+__global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                             const int32_t* __restrict__ idx, int64_t n_out, int HV, int H,
+                                                             uint32_t thr, float keep_scale, uint64_t seed,
+                                                             float* __restrict__ out, int64_t ld_out) {
+  using V = typename Vec<VEC>::T;
+  const int64_t total = n_out * HV;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / HV;
+    const int c = static_cast<int>(e - r * HV) * VEC;
+    const int32_t j = idx[r];
+    V v = V(0.0f);
+    if (j >= 0) v = ld<VEC>(src + j * ld_src + c);
+    if (thr != 0u) {
+      const uint64_t base = static_cast<uint64_t>(r) * static_cast<uint64_t>(H) + static_cast<uint64_t>(c);
+      if constexpr (VEC == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = rr_keep(seed, base + q, thr) ? v[q] * keep_scale : 0.f;
+      } else {
+        v = rr_keep(seed, base, thr) ? v * keep_scale : 0.f;
+      }
+    }
+    st<VEC>(out + r * ld_out + c, v);
+  }
+}
+
 // stage 1 of the deterministic weighted column sum: block b sums its row chunk.  256 threads =
 // RL row-lanes x CG column groups of 4 floats (H = 300 -> 75 groups x 3 row-lanes), so every lane
 // issues 16-byte loads; the row-lanes are combined through LDS in a fixed order.
@@ -212,6 +240,25 @@ int rr_gather_diff_f32(const float* a, int64_t n_a, int64_t ld_a, const int32_t*
   } else {
     gather_diff_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(a, ld_a, ia, m, ld_m, im, n_out, H, out,
                                                                       ld_out);
+  }
+  return rr_launch_status();
+}
+
+int rr_gather_dropout_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int H,
+                          float drop_p, uint64_t drop_seed, float* out, int64_t ld_out, rr_stream_t stream) {
+  RR_CHECK_ARG(src && idx && out && n_src >= 0 && n_out >= 0 && H >= 1 && ld_src >= H && ld_out >= H);
+  RR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  if (n_out == 0) return RR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint32_t thr = rr_drop_threshold(drop_p);
+  const float ks = 1.0f / (1.0f - drop_p);
+  const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(out);
+  if (vec) {
+    gather_dropout_kernel<4><<<rr_grid_for(n_out * (H / 4), 256), 256, 0, s>>>(src, ld_src, idx, n_out, H / 4, H, thr, ks,
+                                                                             drop_seed, out, ld_out);
+  } else {
+    gather_dropout_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, idx, n_out, H, H, thr, ks,
+                                                                         drop_seed, out, ld_out);
   }
   return rr_launch_status();
 }

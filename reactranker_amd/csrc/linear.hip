@@ -201,7 +201,11 @@ __global__ void __launch_bounds__(THREADS) linear_kernel(const LinearParams P) {
   if (m >= a.M) return;
   const int nq = fkq * 4;
   float* crow = a.c + m * a.ldc;
-  const float* rrow = a.residual ? a.residual + m * a.ldr : nullptr;
+  const float* rrow = nullptr;
+  if (a.residual) {
+    const int64_t rr = a.residual_idx ? static_cast<int64_t>(a.residual_idx[m]) : m;
+    if (rr >= 0) rrow = a.residual + rr * a.ldr;
+  }
   const bool evec = flags & F_EPI_VEC;
 #pragma unroll
   for (int tc = 0; tc < NT; ++tc) {
@@ -407,7 +411,11 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
   if (m >= a.M) return;
   const int nq = fkq * 4;
   float* crow = a.c + m * a.ldc;
-  const float* rrow = a.residual ? a.residual + m * a.ldr : nullptr;
+  const float* rrow = nullptr;
+  if (a.residual) {
+    const int64_t rr = a.residual_idx ? static_cast<int64_t>(a.residual_idx[m]) : m;
+    if (rr >= 0) rrow = a.residual + rr * a.ldr;
+  }
   float* prow = a.c_pre ? a.c_pre + m * a.ld_pre : nullptr;
 #pragma unroll
   for (int tc = 0; tc < NT; ++tc) {

@@ -242,6 +242,11 @@ class BatchMolGraph:
     def get_components(self):
         return self.f_atoms, self.f_bonds, self.a2b, self.b2a, self.b2revb, self.a_scope, self.b_scope
 
+    def unique_bonds(self):
+        """(bmap [nB], bmap_t [nB_unique, C]) — bond-row maps of unique(); see there."""
+        self.unique()
+        return self._unique_bonds
+
     def unique(self):
         """De-duplicated view of the batch: (BatchMolGraph of the distinct molecule objects, atom map).
 
@@ -275,12 +280,25 @@ class BatchMolGraph:
             rep = np.repeat(np.arange(len(uidx)), size)
             within = np.arange(int(size.sum())) - np.repeat(np.cumsum(size) - size, size)
             amap[start[rep] + within] = (ustart[rep] + within).astype(np.int32)
-        counts = np.bincount(amap, minlength=hu["nA"])
-        cmax = int(max(1, counts.max()))
-        amap_t = np.full((hu["nA"], cmax), -1, np.int32)
-        order = np.argsort(amap, kind="stable")
-        pos = np.arange(nA) - np.repeat(np.cumsum(counts) - counts, counts)
-        amap_t[amap[order], pos] = order.astype(np.int32)
+        def transpose(mp, n_u):
+            counts = np.bincount(mp, minlength=n_u)
+            cmax = int(max(1, counts.max()))
+            tt = np.full((n_u, cmax), -1, np.int32)
+            order = np.argsort(mp, kind="stable")
+            pos = np.arange(mp.shape[0]) - np.repeat(np.cumsum(counts) - counts, counts)
+            tt[mp[order], pos] = order.astype(np.int32)
+            return tt
+        amap_t = transpose(amap, hu["nA"])
+        # the same maps for directed bonds (shared-prefix path of the reactant encoder)
+        bmap = np.zeros(h["nB"], np.int32)
+        if len(uidx):
+            bsc = np.asarray(self.b_scope, np.int64).reshape(-1, 2)
+            bsu = np.asarray(ub.b_scope, np.int64).reshape(-1, 2)
+            bstart, bsize = bsc[:, 0], bsc[:, 1]
+            rep = np.repeat(np.arange(len(uidx)), bsize)
+            within = np.arange(int(bsize.sum())) - np.repeat(np.cumsum(bsize) - bsize, bsize)
+            bmap[bstart[rep] + within] = (bsu[uidx, 0][rep] + within).astype(np.int32)
+        self._unique_bonds = (bmap, transpose(bmap, hu["nB"]))
         self._unique = (ub, amap, amap_t)
         return self._unique
 

@@ -114,6 +114,15 @@ def gather_diff(a, ia, m, im, H: int, out=None):
     return out
 
 
+def gather_dropout(src, idx, H: int, p: float, seed: int):
+    """out[r] = dropout_r(src[idx[r]]): rows shared by several destinations, each with its own mask."""
+    out = _new(src, idx.shape[0], H)
+    check(lib().rr_gather_dropout_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), idx.shape[0], H, float(p),
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(out), _ld(out), stream()),
+          "rr_gather_dropout_f32")
+    return out
+
+
 def weighted_colsum(x, w, H: int, out, accumulate: bool):
     """out[0:H] (+)= sum_r w[r] x[r]; the padding row's adjoint."""
     n = x.shape[0]
@@ -126,7 +135,7 @@ def weighted_colsum(x, w, H: int, out, accumulate: bool):
 
 def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub_idx=None, a2=None, k2=0, a_mask=None,
            mask_scale=1.0, ldw=None, w_packed=False, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0,
-           out=None, c_pre=None, dz_out=None, dz_accumulate=False):
+           out=None, c_pre=None, dz_out=None, dz_accumulate=False, residual_idx=None):
     """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h)."""
     ref = a1 if a1 is not None else a2
     if out is None:
@@ -140,7 +149,7 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.dz_out, A.ld_dz, A.dz_accumulate = ptr(dz_out), _ld(dz_out), int(dz_accumulate)
     A.w, A.ldw, A.w_packed = ptr(w), (w.stride(0) if ldw is None else ldw), int(w_packed)
     A.bias = ptr(bias)
-    A.residual, A.ldr = ptr(residual), _ld(residual)
+    A.residual, A.ldr, A.residual_idx = ptr(residual), _ld(residual), ptr(residual_idx)
     A.act, A.drop_p, A.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
     A.c, A.ldc = ptr(out), _ld(out)
     A.c_pre, A.ld_pre = ptr(c_pre), _ld(c_pre)
@@ -403,6 +412,83 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
     return gWi, gbi, gWh, gbh, gWo, gbo
 
 
+def mpn_forward_shared(gu, g, bmap, H: int, depth: int, Wi: LinW, Wh: LinW, Wo: LinW, p: float, seed: int):
+    """mpn_forward for a batch whose molecules repeat (every candidate of a query carries the same
+    reactant, train_listwise.py:188): everything BEFORE the first dropout — W_i, relu, the first
+    gather-sum and the first W_h layer (models/mpn.py:80-95) — is identical across the copies, so it
+    runs once per distinct molecule (graph `gu`) and is expanded with each copy's own dropout mask
+    (`bmap`: full bond row -> distinct bond row).  The mask stream and indices are those of the
+    plain path, so results are the same numbers.  Needs depth >= 2."""
+    nA, nB, nBu = g.nA, g.nB, gu.nB
+    inp_u = _new(gu.f_bonds, nBu, H)
+    msg0_u = _new(gu.f_bonds, nBu, H)
+    linear(nBu, H, Wi.pk(FBOND), w_packed=True, a1=gu.f_bonds, k1=FBOND, bias=Wi.b, act=ACT_RELU, out=msg0_u, c_pre=inp_u)
+    a0_u = gather_sum(msg0_u, gu.a2b, H)
+    z1_u = linear(nBu, H, Wh.pk(H), w_packed=True, a1=a0_u, k1=H, a1_idx=gu.b2a, a1_sub=msg0_u, a1_sub_idx=gu.b2revb,
+                  bias=Wh.b, residual=inp_u, act=ACT_RELU)                          # pre-dropout, shared
+    msgs = [None, gather_dropout(z1_u, bmap, H, p, _site_seed(seed, 0))]             # per-copy masks (:97)
+    amsgs = [None]
+    for it in range(1, depth - 1):
+        a_msg = gather_sum(msgs[-1], g.a2b, H)
+        new = linear(nB, H, Wh.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=g.b2a, a1_sub=msgs[-1], a1_sub_idx=g.b2revb,
+                     bias=Wh.b, residual=inp_u, residual_idx=bmap, act=ACT_RELU, drop_p=p, seed=_site_seed(seed, it))
+        amsgs.append(a_msg)
+        msgs.append(new)
+    del inp_u
+    a_last = gather_sum(msgs[-1], g.a2b, H)
+    h = linear(nA, H, Wo.pk(ATOM_FDIM, H), w_packed=True, a1=g.f_atoms, k1=ATOM_FDIM, a2=a_last, k2=H, bias=Wo.b,
+               act=ACT_RELU, drop_p=p, seed=_site_seed(seed, 1000))
+    return h, (msgs, amsgs, a_last, h, (msg0_u, a0_u))
+
+
+def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, Wo: LinW, p: float, saved, dH, sign: float):
+    """Adjoint of mpn_forward_shared.  The per-copy layers run as in mpn_backward; the gradients that reach
+    the shared prefix are summed over the copies (fixed-order segment sums over `bmap_t`) and the prefix is
+    back-propagated once on the distinct molecules — every op there is linear in the gradient, so the sum
+    commutes with it."""
+    msgs, amsgs, a_last, h, (msg0_u, a0_u) = saved
+    nA, nB, nBu = g.nA, g.nB, gu.nB
+    ks = 1.0 / (1.0 - p)
+    gWi, gbi = Wi.grads()
+    gWo, gbo = Wo.grads()
+    gWh, gbh = Wh.grads()
+    wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
+    d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
+    d_msg = gather_sum(d_a, g.b2t, H)
+    _pad_row_fix(d_msg, d_a, g, H)
+    d_inp_full = None
+    wh_started = False
+    for it in reversed(range(1, depth - 1)):                         # per-copy W_h layers
+        first = d_inp_full is None
+        if first:
+            d_inp_full = torch.empty_like(d_msg)
+        wgrad(nB, H, d_msg, gWh, dbias=gbh, mask=msgs[it + 1], mask_scale=ks, x1=amsgs[it], k1=H, x1_idx=g.b2a,
+              x1_sub=msgs[it], x1_sub_idx=g.b2revb, accumulate=wh_started, side=True)
+        wh_started = True
+        d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
+                       dz_out=d_inp_full, dz_accumulate=not first)
+        d_a = gather_sum(d_min, g.a2b_rev_t, H)
+        d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H)
+        _pad_row_fix(d_msg, d_a, g, H)
+    # ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
+    dz1_full = relu_bwd(d_msg, msgs[1], ks)                           # (msgs[1] > 0) <=> kept and z1 > 0
+    dz1_u = gather_sum(dz1_full, bmap_t, H)                           # sum over the copies
+    if d_inp_full is not None:
+        d_inp_u = gather_sum(d_inp_full, bmap_t, H)
+        axpby(1.0, d_inp_u, 1.0, dz1_u, out=d_inp_u)
+    else:
+        d_inp_u = dz1_u.clone()
+    wgrad(nBu, H, dz1_u, gWh, dbias=gbh, x1=a0_u, k1=H, x1_idx=gu.b2a, x1_sub=msg0_u, x1_sub_idx=gu.b2revb,
+          accumulate=wh_started, side=True)
+    d_min_u = linear(nBu, H, Wh.pk_t(0, H), w_packed=True, a1=dz1_u, k1=H)
+    d_a_u = gather_sum(d_min_u, gu.a2b_rev_t, H)
+    d_msg0_u = gather_diff(d_a_u, gu.b2t, d_min_u, gu.b2revb, H)
+    _pad_row_fix(d_msg0_u, d_a_u, gu, H)
+    relu_bwd(d_msg0_u, msg0_u, 1.0, acc=d_inp_u, want_dz=False)       # msg0 = relu(inp)
+    wgrad(nBu, H, d_inp_u, gWi, dbias=gbi, x1=gu.f_bonds, k1=FBOND, side=True)
+    return gWi, gbi, gWh, gbh, gWo, gbo
+
+
 def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Optional[LinW], p: float, seed: int,
                     x, x_sub=None, feat=None, F: int = 0, out_drop_p: float = 0.0, out_seed: int = 0, x_sub_idx=None):
     """MPNDiff.forward (models/mpn.py:170-240).  atom_features = x - x_sub (x_sub=None: x itself);
@@ -577,6 +663,12 @@ class ReactionModelFn(torch.autograd.Function):
         rg, pg = st["r"], st["p_graph"]
         dev = rg.f_bonds.device
         main = torch.cuda.current_stream(dev)
+        px = st.get("prefix")                                        # (distinct reactant graph, bmap, bmap_t) or None
+
+        def enc_r():
+            if px is not None:
+                return mpn_forward_shared(px[0], rg, px[1], H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
+            return mpn_forward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
         if AuxStream.enabled:
             enc[0].pk(FBOND)                                        # shared packed weights: build once, on main
             if enc[1] is not None:
@@ -585,12 +677,12 @@ class ReactionModelFn(torch.autograd.Function):
             aux = AuxStream.get(dev)
             aux.wait_stream(main)
             with torch.cuda.stream(aux):
-                r_h, r_saved = mpn_forward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
+                r_h, r_saved = enc_r()
             p_h, p_saved = mpn_forward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 2))
             main.wait_stream(aux)
             r_h.record_stream(main)
         else:
-            r_h, r_saved = mpn_forward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 1))
+            r_h, r_saved = enc_r()
             p_h, p_saved = mpn_forward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, _site_seed(seed, 2))
         dd = st.get("dedup")                                         # (unique reactant graph, amap, amap_t) or None
         vecs, d_saved = mpndiff_forward(pg, H, st["diff_depth"], dif[0], dif[1], dif[2], p, _site_seed(seed, 3),
@@ -621,7 +713,7 @@ class ReactionModelFn(torch.autograd.Function):
                                                                  x_sub_idx=None if dd is None else dd[1])
         # de-duplicated reactants: d r_h[u] = -(sum over the copies of atom u of d_diff) (fixed-order segment sum)
         d_r = d_diff if dd is None else gather_sum(d_diff, dd[2], H)
-        if AuxStream.enabled and AuxStream.backward:
+        if AuxStream.enabled and AuxStream.backward and st.get("prefix") is None:
             dev = dout.device
             main = torch.cuda.current_stream(dev)
             aux = AuxStream.get(dev)
@@ -639,7 +731,11 @@ class ReactionModelFn(torch.autograd.Function):
                     t.record_stream(main)
         else:
             gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
-            gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0)
+            px = st.get("prefix")
+            if px is not None:
+                gr = mpn_backward_shared(px[0], rg, px[2], H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0)
+            else:
+                gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0)
         SideStream.join(dout.device)                                # weight gradients are complete from here on
         genc = []
         for a, b in zip(gp, gr):                                    # the two encoder passes share weights
