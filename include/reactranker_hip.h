@@ -266,6 +266,18 @@ int rr_gauss_nll_bwd_f32(const float* mean, const float* var, int64_t stride, co
                          int64_t n, const float* gloss, float* dmean, float* dvar, int64_t dstride,
                          rr_stream_t stream);
 
+/* Per-query ranking evaluation on the device — `ranking_metrics` (train/eval.py:475-555) without the
+ * one-forward-per-query loop and the Python lists; same list description as the losses.
+ *   order[off_q + r] = position (inside its list) of the candidate ranked r-th by score, descending, ties
+ *                      keeping the original order (python's stable sorted(..., reverse=True), :516-519)
+ *   stats[q*8 + 0..7] = { top-1 hit, top-25% hit, recall@25%, NDCG1, NDCG2, NDCG25%, NDCG_all   (:521-546,
+ *                         exp gains, compute_NDCG :460-472, python round() for the 25% cut, NDCG2 without
+ *                         discount exactly as the reference computes it),
+ *                         NDCG@10 with exp2 gains of `targets` taken as relevance grades (metrics.py:54-71) }
+ * stats are float64.  The trainer-level numbers are the means over queries. */
+int rr_ranking_metrics_f32(const float* score, int64_t score_stride, const float* targets, const int32_t* seg_off,
+                           int Q, int max_len, int32_t* order, double* stats, rr_stream_t stream);
+
 /* LogCumsumExp along dim 0 of a 1-D tensor (train/loss.py:9-61); n <= 8192.
  * backward keeps the reference's un-shifted exp(x) (:59). */
 int rr_logcumsumexp_fwd_f32(const float* x, int n, float* y, rr_stream_t stream);

@@ -415,6 +415,36 @@ def compute_ndcg_eval(truth, pred):
     return float(np.sum(np.exp(pred) / d) / np.sum(np.exp(truth) / d))
 
 
+def ranking_metrics_from_scores(scores_per_query, targets_per_query):
+    """ranking_metrics (train/eval.py:475-555) on given per-query scores: returns (top1, recall25, top25, NDCG_[4])
+    plus the per-query orders.  Keeps the reference's quirks: python round() for the 25 % cut (:522), stable
+    sorted(..., reverse=True) (:516-519), and NDCG2 computed on nested lists, i.e. without discount (:543)."""
+    top1 = top25 = 0
+    recall, nd, orders = [], [], []
+    for pred, targ in zip(scores_per_query, targets_per_query):
+        pred_scores, target_scores = [float(x) for x in pred], [float(x) for x in targ]
+        n = len(target_scores)
+        sp = sorted(enumerate(pred_scores), key=lambda x: x[1], reverse=True)
+        st = sorted(enumerate(target_scores), key=lambda x: x[1], reverse=True)
+        pidx, tidx = [i for i, _ in sp], [i for i, _ in st]
+        tsorted = [v for _, v in st]
+        orders.append(pidx)
+        if pidx[0] == tidx[0]:
+            top1 += 1
+        len25 = round(n * 0.25)
+        if len25 < 1:
+            len25 = 1
+        ptop, ttop = pidx[:len25], tidx[:len25]
+        if ptop[0] in ttop:
+            top25 += 1
+        recall.append(sum(1 for i in ptop if i in ttop) / len25)
+        prt = [target_scores[i] for i in pidx]
+        nd.append([compute_ndcg_eval([tsorted[0]], [prt[0]]), compute_ndcg_eval([tsorted[:2]], [prt[:2]]),
+                   compute_ndcg_eval(tsorted[:len25], prt[:len25]), compute_ndcg_eval(tsorted, prt)])
+    q = len(orders)
+    return top1 / q, float(np.mean(recall)), top25 / q, np.mean(nd, axis=0), orders
+
+
 def params_from_numpy(w: Dict[str, np.ndarray], requires_grad=False) -> Dict[str, torch.Tensor]:
     out = {}
     for k, v in w.items():

@@ -90,6 +90,7 @@ _SIGS = {
     "rr_mse_bwd_f32": (i32, [c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, i64, c_stream]),
     "rr_gauss_nll_fwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, c_stream]),
     "rr_gauss_nll_bwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
+    "rr_ranking_metrics_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, c_i32p, C.c_void_p, c_stream]),
     "rr_logcumsumexp_fwd_f32": (i32, [c_f32p, i32, c_f32p, c_stream]),
     "rr_logcumsumexp_bwd_f32": (i32, [c_f32p, c_f32p, c_f32p, i32, c_f32p, c_stream]),
     "rr_pack_sizes": (i32, [C.c_void_p, C.c_void_p, i64, C.c_void_p, i32, C.POINTER(i64), C.POINTER(i64),

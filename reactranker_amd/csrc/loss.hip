@@ -430,6 +430,92 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------- ranking metrics (eval.py:475-555)
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(RR_WAVE) ranking_metrics_kernel(const float* __restrict__ score, int64_t sstride,
+                                                                  const float* __restrict__ targets,
+                                                                  const int32_t* __restrict__ seg_off, int L,
+                                                                  int32_t* __restrict__ order,
+                                                                  double* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const int off = seg_off[q], C = seg_off[q + 1] - off;
+  double* st = stats + static_cast<int64_t>(q) * 8;
+  if (C <= 0) {
+    if (lane < 8) st[lane] = 0.0;
+    return;
+  }
+  float* s = sm;
+  float* t = sm + L;
+  int32_t* po = reinterpret_cast<int32_t*>(sm + 2 * L);      // predicted order
+  int32_t* to = reinterpret_cast<int32_t*>(sm + 3 * L);      // target order
+  for (int i = lane; i < C; i += RR_WAVE) {
+    s[i] = score[static_cast<int64_t>(off + i) * sstride];
+    t[i] = targets[off + i];
+  }
+  wave_sync();
+  for (int i = lane; i < C; i += RR_WAVE) {                   // stable descending ranks of both keys
+    const float si = s[i], ti = t[i];
+    int rp = 0, rt = 0;
+    for (int j = 0; j < C; ++j) {
+      const float sj = s[j], tj = t[j];
+      rp += (sj > si || (sj == si && j < i)) ? 1 : 0;
+      rt += (tj > ti || (tj == ti && j < i)) ? 1 : 0;
+    }
+    po[rp] = i;
+    to[rt] = i;
+  }
+  wave_sync();
+  for (int r = lane; r < C; r += RR_WAVE) order[off + r] = po[r];
+  int len25 = static_cast<int>(rint(static_cast<double>(C) * 0.25));   // python round(): half to even (:522)
+  if (len25 < 1) len25 = 1;
+  // recall@25%: predicted top-len25 that are in the target top-len25
+  int hits = 0, hit0 = 0;
+  for (int i = lane; i < len25; i += RR_WAVE) {
+    const int pi = po[i];
+    int in = 0;
+    for (int j = 0; j < len25; ++j) in |= (to[j] == pi) ? 1 : 0;
+    hits += in;
+    if (i == 0) hit0 = in;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { hits += __shfl_xor(hits, o, RR_WAVE); hit0 += __shfl_xor(hit0, o, RR_WAVE); }
+  // DCG sums with exp gains (compute_NDCG) over the first len25 / all positions, and exp2 gains over the first 10
+  double d25 = 0, i25 = 0, dall = 0, iall = 0, d10 = 0, i10 = 0;
+  for (int i = lane; i < C; i += RR_WAVE) {
+    const double disc = log2(static_cast<double>(i) + 2.0);
+    const double gp = exp(static_cast<double>(t[po[i]])), gt = exp(static_cast<double>(t[to[i]]));
+    dall += gp / disc;
+    iall += gt / disc;
+    if (i < len25) { d25 += gp / disc; i25 += gt / disc; }
+    if (i < 10) {
+      d10 += (exp2(static_cast<double>(t[po[i]])) - 1.0) / disc;
+      i10 += (exp2(static_cast<double>(t[to[i]])) - 1.0) / disc;
+    }
+  }
+  d25 = wave_sum_f64(d25); i25 = wave_sum_f64(i25);
+  dall = wave_sum_f64(dall); iall = wave_sum_f64(iall);
+  d10 = wave_sum_f64(d10); i10 = wave_sum_f64(i10);
+  if (lane == 0) {
+    const double p0 = exp(static_cast<double>(t[po[0]])), t0 = exp(static_cast<double>(t[to[0]]));
+    double p2 = p0, t2 = t0;                                  // NDCG2: nested lists -> no discount (:543)
+    if (C > 1) { p2 += exp(static_cast<double>(t[po[1]])); t2 += exp(static_cast<double>(t[to[1]])); }
+    st[0] = (po[0] == to[0]) ? 1.0 : 0.0;
+    st[1] = hit0 ? 1.0 : 0.0;
+    st[2] = static_cast<double>(hits) / static_cast<double>(len25);
+    st[3] = p0 / t0;
+    st[4] = p2 / t2;
+    st[5] = d25 / i25;
+    st[6] = dall / iall;
+    st[7] = d10 / i10;
+  }
+}
+
 // ---------------------------------------------------------------- standalone LogCumsumExp
 __global__ void __launch_bounds__(RR_WAVE) lce_fwd_kernel(const float* __restrict__ x, int n, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -646,6 +732,19 @@ int rr_gauss_nll_bwd_f32(const float* mean, const float* var, int64_t stride, co
   if (n == 0) return RR_OK;
   pointwise_bwd_kernel<<<pointwise_blocks(n), 256, 0, static_cast<hipStream_t>(stream)>>>(
       mean, var, stride, targets, n, 1, gloss, dmean, dvar, dstride);
+  return rr_launch_status();
+}
+
+int rr_ranking_metrics_f32(const float* score, int64_t score_stride, const float* targets, const int32_t* seg_off,
+                           int Q, int max_len, int32_t* order, double* stats, rr_stream_t stream) {
+  RR_CHECK_ARG(list_args_ok(score, targets, seg_off, Q, max_len) && order && stats && score_stride >= 1);
+  if (max_len > kMaxLen) return RR_ERR_UNSUPPORTED;
+  if (Q == 0) return RR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int L = max_len > 0 ? max_len : 1;
+  const size_t lds = 4u * L * sizeof(float);
+  if (set_lds(ranking_metrics_kernel, lds) != RR_OK) return RR_ERR_LAUNCH;
+  ranking_metrics_kernel<<<Q, RR_WAVE, lds, s>>>(score, score_stride, targets, seg_off, L, order, stats);
   return rr_launch_status();
 }
 

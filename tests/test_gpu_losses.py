@@ -142,3 +142,34 @@ def test_strided_score_column_and_query_permutation_invariance():
     idx = np.concatenate([np.arange(q * 64, (q + 1) * 64) for q in perm])
     c = RL.MLEloss()(out[:, 0].contiguous()[idx], scope, targets[idx], 0)
     close(c, a, tol=1e-6, what="query order")
+
+
+def test_ranking_metrics_kernel_against_reference_loop(golden_dir):
+    """On-device ranking_metrics vs the numbers the reference's own loop produced (tests/golden/eval_metrics.npz)
+    and vs the oracle on random lists incl. ties and C > 64."""
+    from reactranker_amd import eval as RE
+    E = np.load(golden_dir + "/eval_metrics.npz")
+    for name in ("plain", "ties"):
+        scope = E[name + ".scope"].tolist()
+        sc = torch.tensor(E[name + ".scores"]).cuda()
+        tg = torch.tensor(E[name + ".targets"])
+        top1, rec, top25, nd = RE.ranking_metrics_from_scores(sc, scope, tg, 0)
+        assert top1 == float(E[name + ".top1"]) and top25 == float(E[name + ".top25"])
+        assert abs(rec - float(E[name + ".recall25"])) < 1e-12
+        assert np.allclose(nd, E[name + ".ndcg"], rtol=0, atol=1e-12)
+        stats, order = RE.ranking_stats(sc, scope, tg, 0)
+        assert np.array_equal(order.cpu().numpy(), E[name + ".order"])          # bit-exact candidate ordering
+        rel = torch.tensor(np.maximum(np.round(E[name + ".targets"].astype(np.float64) * 2 + 3), 0).astype(np.float32))
+        nd10 = RE.ndcg_at_k(sc, scope, rel, 0)
+        ok = ~np.isnan(E[name + ".ndcg10_rel"])
+        assert np.allclose(nd10[ok], E[name + ".ndcg10_rel"][ok], rtol=0, atol=1e-12)
+    rng = np.random.default_rng(5)
+    scope = [1, 2, 64, 65, 130, 7, 300]
+    sc = [np.round(rng.standard_normal(c), 1).astype(np.float32) for c in scope]
+    tg = [rng.standard_normal(c).astype(np.float32) for c in scope]
+    r_top1, r_rec, r_top25, r_nd, r_orders = O.ranking_metrics_from_scores(sc, tg)
+    top1, rec, top25, nd = RE.ranking_metrics_from_scores(torch.tensor(np.concatenate(sc)).cuda(), scope,
+                                                          torch.tensor(np.concatenate(tg)), 0)
+    assert (top1, top25) == (r_top1, r_top25) and abs(rec - r_rec) < 1e-12 and np.allclose(nd, r_nd, rtol=0, atol=1e-12)
+    _, order = RE.ranking_stats(torch.tensor(np.concatenate(sc)).cuda(), scope, torch.tensor(np.concatenate(tg)), 0)
+    assert np.array_equal(order.cpu().numpy(), np.concatenate(r_orders).astype(np.int32))

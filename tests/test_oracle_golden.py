@@ -183,3 +183,18 @@ def test_metrics_known_answers(golden_dir):
         assert abs(O.ndcg(rel, 5, "identity") - float(Mx[f"rand{i}.ndcg5_id"])) < 1e-12
         assert abs(O.compute_ndcg_eval(Mx[f"rand{i}.truth"], Mx[f"rand{i}.pred"]) - float(Mx[f"rand{i}.eval_ndcg"])) < 1e-12
         assert O.ranking_order(Mx[f"rand{i}.scores"].tolist()) == Mx[f"rand{i}.order"].tolist()
+
+
+def test_ranking_metrics_against_reference_loop(golden_dir):
+    """oracle.ranking_metrics_from_scores vs the reference's own ranking_metrics run on preset scores."""
+    E = np.load(golden_dir + "/eval_metrics.npz")
+    for name in ("plain", "ties"):
+        scope = E[name + ".scope"].tolist()
+        offs = np.cumsum([0] + scope)
+        sc = [E[name + ".scores"][a:b] for a, b in zip(offs[:-1], offs[1:])]
+        tg = [E[name + ".targets"][a:b] for a, b in zip(offs[:-1], offs[1:])]
+        top1, rec, top25, nd, orders = O.ranking_metrics_from_scores(sc, tg)
+        assert top1 == float(E[name + ".top1"]) and top25 == float(E[name + ".top25"])
+        assert abs(rec - float(E[name + ".recall25"])) < 1e-15
+        assert np.allclose(nd, E[name + ".ndcg"], rtol=0, atol=1e-14)
+        assert np.array_equal(np.concatenate(orders).astype(np.int32), E[name + ".order"])

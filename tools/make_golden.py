@@ -425,6 +425,49 @@ def gen_metrics():
     print("wrote metrics.npz")
 
 
+def gen_eval_metrics():
+    """Drive the reference's own ranking_metrics (train/eval.py:475-555) with preset scores."""
+    rng = np.random.default_rng(77)
+    out = {}
+    for name, scope, decimals in (("plain", [1, 2, 3, 8, 10, 64, 5, 7], 6), ("ties", [4, 9, 16, 6, 2, 33], 1)):
+        scores = [np.round(rng.standard_normal(c) * 1.3, decimals).astype(np.float32) for c in scope]
+        targets = [np.round(rng.standard_normal(c), decimals).astype(np.float32) for c in scope]
+
+        class _Model:
+            def __init__(self):
+                self.i = 0
+
+            def eval(self):
+                pass
+
+            def __call__(self, r, p, gpu=None, add_features=None):
+                t = torch.tensor(scores[self.i])
+                self.i += 1
+                return t
+
+        class _DP:
+            def generate_batch_per_query(self, **kw):
+                for c, t in zip(scope, targets):
+                    yield np.array([["r", "p%d" % i] for i in range(c)]), t, None
+        top1, recall25, top25, nd = ref_eval.ranking_metrics(_Model(), None, _DP(), _StubGraphs(), show_info=False)
+        out[name + ".scope"] = np.asarray(scope, np.int32)
+        out[name + ".scores"] = np.concatenate(scores)
+        out[name + ".targets"] = np.concatenate(targets)
+        out[name + ".top1"], out[name + ".recall25"], out[name + ".top25"] = np.float64(top1), np.float64(recall25), np.float64(top25)
+        out[name + ".ndcg"] = np.asarray(nd, np.float64)
+        # per-query pieces, recomputed with the reference's own helpers for finer-grained checks
+        orders, nd10 = [], []
+        for sc, tg in zip(scores, targets):
+            order = [k for k, _ in sorted(enumerate(sc.tolist()), key=lambda x: x[1], reverse=True)]
+            orders.extend(order)
+            rel = np.maximum(np.round(tg.astype(np.float64) * 2 + 3), 0)      # non-negative grades for exp2 gains
+            nd10.append(ref_metrics.NDCG(10, "exp2").evaluate(rel[order]) if rel.max() > 0 else np.nan)
+        out[name + ".order"] = np.asarray(orders, np.int32)
+        out[name + ".ndcg10_rel"] = np.asarray(nd10, np.float64)
+    np.savez_compressed(os.path.join(OUT, "eval_metrics.npz"), **out)
+    print("wrote eval_metrics.npz", {k: v for k, v in out.items() if k.endswith((".top1", ".recall25", ".top25"))})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -433,3 +476,4 @@ if __name__ == "__main__":
         gen_model_case(case)
     gen_losses()
     gen_metrics()
+    gen_eval_metrics()
