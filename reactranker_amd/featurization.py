@@ -365,3 +365,33 @@ def device_graph_of(batch, gpu) -> DeviceGraph:
 def mol2graph(smiles_batch):
     """Reference featurization.py:338-350 — needs RDKit."""
     return BatchMolGraph([MolGraph(s) for s in smiles_batch])
+
+
+# ---- packed on-disk format (SURVEY.md section 8f-2): the packer's host arrays as one .npz per batch ------------
+_PACK_KEYS = ("f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope", "a2b_rev_t", "b2t", "a2a_t", "npad",
+              "atom2mol")
+
+
+def save_packed(batch: BatchMolGraph, path: str) -> None:
+    """Write a packed batch (features, index arrays, backward tables) so a dataset is packed once, not per epoch
+    (the reference re-runs BatchMolGraph's Python list packing for every batch of every epoch)."""
+    h = batch._host
+    np.savez(path, **{k: h[k] for k in _PACK_KEYS},
+             meta=np.asarray([h["nA"], h["nB"], h["K"], h["M"], h["atom_fdim"], h["bond_fdim"]], np.int64),
+             b_scope=np.asarray(batch.b_scope, np.int64).reshape(-1, 2))
+
+
+def load_packed(path: str) -> BatchMolGraph:
+    """Inverse of save_packed: a BatchMolGraph backed by the stored arrays (no re-packing)."""
+    d = np.load(path if path.endswith(".npz") else path + ".npz")
+    b = BatchMolGraph.__new__(BatchMolGraph)
+    nA, nB, K, M, afd, bfd = (int(v) for v in d["meta"])
+    b._host = {k: np.ascontiguousarray(d[k]) for k in _PACK_KEYS}
+    b._host.update(nA=nA, nB=nB, K=K, M=M, atom_fdim=afd, bond_fdim=bfd)
+    b.smiles_batch, b.n_mols = [""] * M, M
+    b.atom_fdim, b.bond_fdim = get_atom_fdim(), get_bond_fdim() + get_atom_fdim()
+    b.n_atoms, b.n_bonds, b.max_num_bonds = nA, nB, K
+    b.a_scope = [tuple(int(v) for v in r) for r in b._host["a_scope"]]
+    b.b_scope = [tuple(int(v) for v in r) for r in d["b_scope"]]
+    b.b2b, b._dev, b._specs = None, {}, None
+    return b

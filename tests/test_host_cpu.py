@@ -146,3 +146,32 @@ def test_product_path_fails_loudly_without_gpu():
     from reactranker_amd.loss import MLEloss
     with pytest.raises(RuntimeError):
         MLEloss()(torch.zeros(3), [3], torch.zeros(3), None)
+
+
+def test_packed_format_roundtrip(tmp_path):
+    qb = synth.make_queries(1, 2, [3, 4])
+    b = featurization.BatchMolGraph(qb.p_specs, K=4)
+    path = str(tmp_path / "batch.npz")
+    featurization.save_packed(b, path)
+    c = featurization.load_packed(path)
+    for k in featurization._PACK_KEYS:
+        assert np.array_equal(b._host[k], c._host[k]), k
+    assert c.a_scope == b.a_scope and c.b_scope == b.b_scope and c.max_num_bonds == 4 and c.n_mols == b.n_mols
+    assert torch.equal(c.get_components()[0], b.get_components()[0])
+
+
+def test_unique_maps_are_consistent():
+    qb = synth.make_queries(3, 3, [4, 2, 5], atoms_lo=4, atoms_hi=7)
+    b = featurization.BatchMolGraph(qb.r_specs, K=4)
+    ub, amap, amap_t = b.unique()
+    bmap, bmap_t = b.unique_bonds()
+    assert ub.n_mols == 3 and ub.max_num_bonds == 4
+    assert np.array_equal(b._host["f_atoms"], ub._host["f_atoms"][amap])
+    assert np.array_equal(b._host["f_bonds"], ub._host["f_bonds"][bmap])
+    assert np.array_equal(amap[b._host["b2a"]], ub._host["b2a"][bmap])
+    assert np.array_equal(bmap[b._host["b2revb"]], ub._host["b2revb"][bmap])
+    assert np.array_equal(bmap[b._host["a2b"]], ub._host["a2b"][amap])
+    for mp, tt in ((amap, amap_t), (bmap, bmap_t)):
+        for u in range(tt.shape[0]):
+            rows = tt[u][tt[u] >= 0]
+            assert np.array_equal(np.sort(rows), np.flatnonzero(mp == u))
