@@ -256,11 +256,24 @@ __global__ void __launch_bounds__(THREADS) linear_kernel(const LinearParams P) {
 }
 
 
+#ifdef RR_TRACE
+__device__ unsigned long long* rr_trace_buf = nullptr;
+#define RR_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (rr_trace_buf && threadIdx.x == 0 && blockIdx.y == 0)                                             \
+      rr_trace_buf[static_cast<size_t>(blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();     \
+  } while (0)
+#else
+#define RR_STAMP(slot)
+#endif
+
 // ------------------------------------------------------------------------ fast path
 // Same math as linear_kernel, for the hot case: every A source 16-byte addressable and W in
 // the packed layout of rr_pack_weight_f32 ([N][r16(k1) + r16(k2)], zero padded).  The loader
-// is straight-line code: W needs no bounds logic at all (row index clamped, pad columns are
-// zeros), A chunks are loaded unconditionally from (valid ? row + k : dummy), and every
+// is straight-line code: the W panel of a k-tile goes global -> LDS by LDS-DMA (global_load_lds,
+// no VGPR round trip, no ds_write; row index clamped, pad columns are zeros, the XOR swizzle of
+// the LDS image is applied to the per-lane source address), A chunks are loaded
+// unconditionally from (valid ? row + k : dummy), and every
 // fix-up (tail columns, invalid rows, the subtraction / ReLU mask of MODE 1 / 2) happens when
 // the registers are written to LDS, i.e. AFTER the k-tile's MFMAs.  Nothing uses a loaded
 // value before that point, so the compiler keeps all loads of tile t+1 in flight across the
@@ -268,13 +281,21 @@ __global__ void __launch_bounds__(THREADS) linear_kernel(const LinearParams P) {
 template <int NT, int MODE>
 __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearParams P) {
   constexpr int BN = 16 * NT;
-  constexpr int B_ITERS = (BN * 4 + THREADS - 1) / THREADS;
   __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BK];
 
   const rr_linear_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
+  RR_STAMP(0);
+#ifdef RR_TRACE
+  if (rr_trace_buf && threadIdx.x == 0 && blockIdx.y == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    rr_trace_buf[static_cast<size_t>(blockIdx.x) * 8 + 4] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+  }
+#endif
 
   const int srow = tid >> 2, skq = tid & 3;
   const int64_t sm = m0 + srow;
@@ -304,13 +325,17 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
   }
   float* dzrow = nullptr;                             // MODE 2 side output: dz_out (+)= masked operand
   if (MODE == 2 && a.dz_out && sm < a.M && blockIdx.y == 0) dzrow = a.dz_out + sm * a.ld_dz;
-  // W rows staged by this thread (row index clamped into [0, N-1]: columns >= N are never stored)
-  const float* wrow[B_ITERS];
+  // W panel by LDS-DMA: wave-instruction j fills column tile j (16 rows x 4 chunks = 1 KiB, lane-linear
+  // in LDS); the XOR swizzle of the LDS image goes on each lane's SOURCE column chunk.
+  constexpr int G_ITERS = (NT + 3) / 4;
+  const int uwave = __builtin_amdgcn_readfirstlane(wave) & 3;
+  const float* wsrc[G_ITERS];
 #pragma unroll
-  for (int it = 0; it < B_ITERS; ++it) {
-    int n = n0 + ((it * THREADS + tid) >> 2);
+  for (int it = 0; it < G_ITERS; ++it) {
+    const int wr = (it * 4 + uwave) * 16 + (lane >> 2);
+    int n = n0 + wr;
     if (n > a.N - 1) n = a.N - 1;
-    wrow[it] = a.w + static_cast<int64_t>(n) * a.ldw + skq * 4;
+    wsrc[it] = a.w + static_cast<int64_t>(n) * a.ldw + 4 * swz(wr, lane & 3);
   }
   const int k1p = r16(a.k1);
 
@@ -320,7 +345,6 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
 
   const int nk = P.t1 + P.t2;
   f32x4 ra, rs, rc;
-  f32x4 rb[B_ITERS];
 
   auto issue = [&](int kt) {                          // pure loads, no arithmetic on the results
     const bool seg1 = kt < P.t1;
@@ -333,8 +357,14 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
       if (a.dz_accumulate) rc = ld4((dzrow != nullptr && kl < ks) ? dzrow + kl : dummy);
     }
     const int kw = seg1 ? kt * BK : k1p + (kt - P.t1) * BK;
+    float* Bd = lds[kt & 1] + BM * BK;
 #pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) rb[it] = ld4(wrow[it] + kw);
+    for (int it = 0; it < G_ITERS; ++it) {
+      const int j = it * 4 + uwave;
+      if (j < NT)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[it] + kw),
+                                         (__attribute__((address_space(3))) void*)(Bd + j * 16 * BK), 16, 0, 0);
+    }
   };
   auto commit = [&](int kt, int buf) {                // fix-ups + LDS stores (first use of the loads)
     const bool seg1 = kt < P.t1;
@@ -366,16 +396,12 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
     float* As = lds[buf];
     float* Bs = lds[buf] + BM * BK;
     *reinterpret_cast<f32x4*>(As + srow * BK + 4 * swz(srow, skq)) = v;
-#pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) {
-      const int wr = (it * THREADS + tid) >> 2;
-      if (wr < BN) *reinterpret_cast<f32x4*>(Bs + wr * BK + 4 * swz(wr, skq)) = rb[it];
-    }
   };
 
   issue(0);
   commit(0, 0);
   __syncthreads();
+  RR_STAMP(1);
 
   const int fr = lane & 15, fkq = lane >> 4;
   const int a_off = (wave * 16 + fr) * BK + 4 * swz(fr, fkq);
@@ -407,8 +433,13 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
   }
 
   // ---- epilogue (vector form only: the fast path requires F_EPI_VEC)
+  RR_STAMP(2);
   const int64_t m = m0 + wave * 16 + fr;
+#ifndef RR_TRACE
   if (m >= a.M) return;
+#else
+  if (m >= a.M) { RR_STAMP(3); return; }
+#endif
   const int nq = fkq * 4;
   float* crow = a.c + m * a.ldc;
   const float* rrow = nullptr;
@@ -417,27 +448,48 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
     if (rr >= 0) rrow = a.residual + rr * a.ldr;
   }
   float* prow = a.c_pre ? a.c_pre + m * a.ld_pre : nullptr;
+  // tiles in groups: all bias / residual loads of a group are in flight together (one wait per group
+  // instead of one dependent round trip per tile)
+  constexpr int EG = 5;
+  const bool has_bias = a.bias != nullptr, has_res = rrow != nullptr;
 #pragma unroll
-  for (int tc = 0; tc < NT; ++tc) {
-    const int n = n0 + tc * 16 + nq;
-    if (n >= a.N) continue;
-    f32x4 v = acc[tc];
-    if (a.bias) v = v + ld4(a.bias + n);
-    if (rrow) v = v + ld4(rrow + n);
-    if (prow) *reinterpret_cast<f32x4*>(prow + n) = v;
-    if (a.act == RR_ACT_RELU) {
-      v.x = fmaxf(v.x, 0.f);
-      v.y = fmaxf(v.y, 0.f);
-      v.z = fmaxf(v.z, 0.f);
-      v.w = fmaxf(v.w, 0.f);
-    }
-    if (P.drop_thr != 0u) {
-      const uint64_t base = static_cast<uint64_t>(m) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
+  for (int t0 = 0; t0 < NT; t0 += EG) {
+    f32x4 bv[EG], rv[EG];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = rr_keep(a.drop_seed, base + e, P.drop_thr) ? v[e] * P.keep_scale : 0.f;
+    for (int g = 0; g < EG; ++g) {
+      const int n = n0 + (t0 + g) * 16 + nq;
+      const bool ok = (t0 + g < NT) && n < a.N;
+      bv[g] = (has_bias && ok) ? ld4(a.bias + n) : f32x4(0.f);
+      rv[g] = (has_res && ok) ? ld4(rrow + n) : f32x4(0.f);
     }
-    *reinterpret_cast<f32x4*>(crow + n) = v;
+#pragma unroll
+    for (int g = 0; g < EG; ++g) {
+      if (t0 + g >= NT) continue;
+      const int tc = t0 + g;
+      const int n = n0 + tc * 16 + nq;
+      if (n >= a.N) continue;
+      f32x4 v = acc[tc];
+      if (has_bias) v = v + bv[g];
+      if (has_res) v = v + rv[g];
+      if (prow) *reinterpret_cast<f32x4*>(prow + n) = v;
+      if (a.act == RR_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+      }
+      if (P.drop_thr != 0u) {
+        const uint64_t base = static_cast<uint64_t>(m) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rr_keep(a.drop_seed, base + e, P.drop_thr) ? v[e] * P.keep_scale : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(crow + n) = v;
+    }
   }
+#ifdef RR_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RR_STAMP(3);
+#endif
 }
 
 // dst = zero-padded packed copy of a weight (or of its transpose) for the fast path
@@ -874,6 +926,12 @@ inline bool vec_ok(const float* p, int64_t ld) { return p && rr_aligned16(p) && 
 }  // namespace
 
 extern "C" {
+
+#ifdef RR_TRACE
+int rr_debug_set_trace(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(rr_trace_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   RR_CHECK_ARG(args);

@@ -29,6 +29,10 @@ def t(fn, n=12):
 fl = 2.0 * nB * H * H
 res = {}
 res["lin_m1"] = t(lambda: Fn.linear(nB, H, W.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=b2a, a1_sub=msg, a1_sub_idx=b2r, bias=W.b, residual=inp, act=1, drop_p=0.1, seed=5, out=out))
+res["m1_bare"] = t(lambda: Fn.linear(nB, H, W.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=b2a, a1_sub=msg, a1_sub_idx=b2r, out=out))
+res["m1_noidx"] = t(lambda: Fn.linear(nB, H, W.pk(H), w_packed=True, a1=msg, k1=H, a1_sub=inp, out=out))
+res["m0_idx"] = t(lambda: Fn.linear(nB, H, W.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=b2a, out=out))
+res["m0_idxrev"] = t(lambda: Fn.linear(nB, H, W.pk(H), w_packed=True, a1=msg, k1=H, a1_idx=b2r, out=out))
 res["lin_m0"] = t(lambda: Fn.linear(nB, H, W.pk(H), w_packed=True, a1=msg, k1=H, out=out))
 msg2 = torch.randn(nB, 2 * H, device=dev)
 W2 = Fn.LinW(torch.randn(H, 2 * H, device=dev) / 24, None)
