@@ -260,8 +260,11 @@ __global__ void __launch_bounds__(THREADS) linear_kernel(const LinearParams P) {
 __device__ unsigned long long* rr_trace_buf = nullptr;
 #define RR_STAMP(slot)                                                                                   \
   do {                                                                                                   \
-    if (rr_trace_buf && threadIdx.x == 0 && blockIdx.y == 0)                                             \
+    if (rr_trace_buf && threadIdx.x == 0 && blockIdx.y == 0) {                                           \
       rr_trace_buf[static_cast<size_t>(blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();     \
+      if ((slot) == 1) rr_trace_buf[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memtime(); \
+      if ((slot) == 2) rr_trace_buf[static_cast<size_t>(blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memtime(); \
+    }                                                                                                    \
   } while (0)
 #else
 #define RR_STAMP(slot)

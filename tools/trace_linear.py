@@ -24,6 +24,13 @@ def run():
         Fn.linear(nB, H, W.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=b2a, a1_sub=msg, a1_sub_idx=b2r, bias=W.b, residual=inp, act=1, drop_p=0.1, seed=5, out=out)
 for _ in range(3): run()
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize()
+print(f"back-to-back x10: {e0.elapsed_time(e1) * 100:.1f} us per launch")
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+print(f"single launch: {e0.elapsed_time(e1) * 1000:.1f} us")
 L._handle if False else None
 fn = C.CDLL(_lib.LIB_PATH).rr_debug_set_trace
 fn.argtypes = [C.c_void_p]; fn.restype = C.c_int
@@ -34,6 +41,9 @@ t0 = t[:, 0].min()
 st, pro, kl, ep = (t[:, 0] - t0) / 100.0, (t[:, 1] - t[:, 0]) / 100.0, (t[:, 2] - t[:, 1]) / 100.0, (t[:, 3] - t[:, 2]) / 100.0
 end = (t[:, 3] - t0) / 100.0
 print(f"mode {mode}: {nwg} workgroups, kernel span {end.max():.1f} us")
+clk = (t[:, 6] - t[:, 5]) / np.maximum(1, (t[:, 2] - t[:, 1])) * 100.0      # shader cycles per us -> MHz
+q = np.percentile(clk, [0, 10, 50, 90, 100])
+print(f"  shader clock during the k-loop (s_memtime / s_memrealtime): min {q[0]:.0f} p10 {q[1]:.0f} p50 {q[2]:.0f} p90 {q[3]:.0f} max {q[4]:.0f} MHz")
 order = np.argsort(st)
 for name, v in (("start", st), ("prologue", pro), ("k-loop", kl), ("epilogue", ep), ("end", end)):
     q = np.percentile(v, [0, 10, 50, 90, 100])
