@@ -46,6 +46,23 @@ __device__ __forceinline__ int swz(int row, int kq) { return kq ^ ((0 - (row >> 
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// LDS-DMA: 16 bytes per lane, global -> LDS at (wave-uniform byte address lds_dst) + lane * 16, no VGPR
+// destination.  Written as asm so that hipcc does not track it: its own bookkeeping treats an LDS-DMA in
+// flight as a may-alias LDS write and drains it (vmcnt(0)) in front of the next ds_read as soon as the
+// kernel has a second __shared__ object, which serialises the panel fetch with the MFMA block.  The caller
+// waits for it explicitly (rr_wait_vm0) before the barrier that publishes the buffer.
+__device__ __forceinline__ void rr_glds16(const float* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void rr_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t rr_lds_addr(const float* p) {
+  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) float*)p));
+}
+
 // 4 consecutive floats p[k..k+3] of a row with `ks` valid columns; columns >= ks read as 0.
 __device__ __forceinline__ f32x4 load_chunk(const float* p, int k, int ks, bool vec) {
   f32x4 v = f32x4(0.f);
@@ -364,9 +381,7 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) {
       const int j = it * 4 + uwave;
-      if (j < NT)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[it] + kw),
-                                         (__attribute__((address_space(3))) void*)(Bd + j * 16 * BK), 16, 0, 0);
+      if (j < NT) rr_glds16(wsrc[it] + kw, rr_lds_addr(Bd + j * 16 * BK));
     }
   };
   auto commit = [&](int kt, int buf) {                // fix-ups + LDS stores (first use of the loads)
@@ -403,6 +418,7 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
 
   issue(0);
   commit(0, 0);
+  rr_wait_vm0();                                       // the LDS-DMA of the first W panel
   __syncthreads();
   RR_STAMP(1);
 
@@ -432,6 +448,7 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
       }
     }
     if (more) commit(kt + 1, cur ^ 1);
+    rr_wait_vm0();                                     // W panel of tile kt+1 has landed in LDS
     __syncthreads();
   }
 
