@@ -302,6 +302,7 @@ template <int NT, int MODE>
 __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearParams P) {
   constexpr int BN = 16 * NT;
   __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) float bias_s[BN];
 
   const rr_linear_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -416,6 +417,10 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
     *reinterpret_cast<f32x4*>(As + srow * BK + 4 * swz(srow, skq)) = v;
   };
 
+  if (tid < BN / 4) {                                  // bias slice of this column block -> LDS (read in the epilogue)
+    const int n = n0 + tid * 4;
+    *reinterpret_cast<f32x4*>(bias_s + tid * 4) = ld4((a.bias && n < a.N) ? a.bias + n : dummy);
+  }
   issue(0);
   commit(0, 0);
   rr_wait_vm0();                                       // the LDS-DMA of the first W panel
@@ -452,58 +457,75 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
     __syncthreads();
   }
 
-  // ---- epilogue (vector form only: the fast path requires F_EPI_VEC)
+  // ---- epilogue (vector form only: the fast path requires F_EPI_VEC).
+  // vmcnt retires loads and stores in issue order, so a wait for a load that was issued after a
+  // store also waits for that store's write acknowledge.  The tile loop is therefore kept free of
+  // path-dependent memory operations (unconditional loads from a safe address, selects instead of
+  // branches, bias from LDS) and the residual chunks run D tiles ahead in a register ring: a store
+  // is only ever waited for D tiles after it was issued, instead of one write round trip per tile.
   RR_STAMP(2);
   const int64_t m = m0 + wave * 16 + fr;
-#ifndef RR_TRACE
-  if (m >= a.M) return;
-#else
-  if (m >= a.M) { RR_STAMP(3); return; }
-#endif
+  const bool row_ok = m < a.M;
+  const int64_t mc = row_ok ? m : a.M - 1;
   const int nq = fkq * 4;
-  float* crow = a.c + m * a.ldc;
+  float* crow = a.c + mc * a.ldc;
   const float* rrow = nullptr;
   if (a.residual) {
-    const int64_t rr = a.residual_idx ? static_cast<int64_t>(a.residual_idx[m]) : m;
+    const int64_t rr = a.residual_idx ? static_cast<int64_t>(a.residual_idx[mc]) : mc;
     if (rr >= 0) rrow = a.residual + rr * a.ldr;
   }
-  float* prow = a.c_pre ? a.c_pre + m * a.ld_pre : nullptr;
-  // tiles in groups: all bias / residual loads of a group are in flight together (one wait per group
-  // instead of one dependent round trip per tile)
-  constexpr int EG = 5;
-  const bool has_bias = a.bias != nullptr, has_res = rrow != nullptr;
-#pragma unroll
-  for (int t0 = 0; t0 < NT; t0 += EG) {
-    f32x4 bv[EG], rv[EG];
-#pragma unroll
-    for (int g = 0; g < EG; ++g) {
-      const int n = n0 + (t0 + g) * 16 + nq;
-      const bool ok = (t0 + g < NT) && n < a.N;
-      bv[g] = (has_bias && ok) ? ld4(a.bias + n) : f32x4(0.f);
-      rv[g] = (has_res && ok) ? ld4(rrow + n) : f32x4(0.f);
+  const bool has_bias = a.bias != nullptr;
+  const bool relu = a.act == RR_ACT_RELU;
+  auto finish = [&](f32x4 v, int n) {                  // activation + dropout + store of one chunk
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
     }
+    if (P.drop_thr != 0u) {
+      const uint64_t base = static_cast<uint64_t>(m) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
 #pragma unroll
-    for (int g = 0; g < EG; ++g) {
-      if (t0 + g >= NT) continue;
-      const int tc = t0 + g;
+      for (int e = 0; e < 4; ++e) v[e] = rr_keep(a.drop_seed, base + e, P.drop_thr) ? v[e] * P.keep_scale : 0.f;
+    }
+    if (row_ok && n < a.N) *reinterpret_cast<f32x4*>(crow + n) = v;
+  };
+  if (a.c_pre) {                                       // pre-activation side output (W_i layers): plain loop
+    float* prow = a.c_pre + mc * a.ld_pre;
+#pragma unroll
+    for (int tc = 0; tc < NT; ++tc) {
       const int n = n0 + tc * 16 + nq;
-      if (n >= a.N) continue;
       f32x4 v = acc[tc];
-      if (has_bias) v = v + bv[g];
-      if (has_res) v = v + rv[g];
-      if (prow) *reinterpret_cast<f32x4*>(prow + n) = v;
-      if (a.act == RR_ACT_RELU) {
-        v.x = fmaxf(v.x, 0.f);
-        v.y = fmaxf(v.y, 0.f);
-        v.z = fmaxf(v.z, 0.f);
-        v.w = fmaxf(v.w, 0.f);
-      }
-      if (P.drop_thr != 0u) {
-        const uint64_t base = static_cast<uint64_t>(m) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
+      if (has_bias) v = v + *reinterpret_cast<const f32x4*>(bias_s + tc * 16 + nq);
+      if (rrow && n < a.N) v = v + ld4(rrow + n);
+      if (row_ok && n < a.N) *reinterpret_cast<f32x4*>(prow + n) = v;
+      finish(v, n);
+    }
+  } else {
+    const bool res_ok = rrow != nullptr;
+    const float* rbase = res_ok ? rrow : dummy;
+    constexpr int D = 4;
+    f32x4 ring[D + 1];
+    auto ldres = [&](int tc) {
+      const int n = n0 + tc * 16 + nq;
+      return ld4(rbase + (n < a.N ? n : 0));
+    };
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rr_keep(a.drop_seed, base + e, P.drop_thr) ? v[e] * P.keep_scale : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(crow + n) = v;
+    for (int t = 0; t < D; ++t)
+      if (t < NT) ring[t] = ldres(t);
+#pragma unroll
+    for (int tc = 0; tc < NT; ++tc) {
+      const int n = n0 + tc * 16 + nq;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + tc * 16 + nq);
+      f32x4 v = acc[tc];
+      const f32x4 vb = v + b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = has_bias ? vb[e] : v[e];
+      const f32x4 vr = v + ring[tc % (D + 1)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = res_ok ? vr[e] : v[e];
+      if (tc + D < NT) ring[(tc + D) % (D + 1)] = ldres(tc + D);
+      finish(v, n);
     }
   }
 #ifdef RR_TRACE
