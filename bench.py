@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="also time forward+loss alone (reported as extra)")
     ap.add_argument("--no-side-stream", action="store_true", help="run weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="run the reactant encoder on the main stream")
+    ap.add_argument("--aux-backward", action="store_true", help="also run the reactant encoder's backward on the aux stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +171,8 @@ def main():
 
     Fn.SideStream.enabled = not args.no_side_stream
     Fn.AuxStream.enabled = not args.no_aux_stream
+    if args.aux_backward:
+        Fn.AuxStream.backward = True
     torch.manual_seed(0)                                  # identical replicas
     model = build_model(hidden_size=args.hidden, mpnn_depth=args.depth, mpnn_diff_depth=args.depth, ffn_depth=3,
                         use_bias=True, dropout=args.dropout, task_num=1, ffn_last_layer="with_softplus",

@@ -718,14 +718,19 @@ __global__ void __launch_bounds__(THREADS) wgrad_kernel(const WgradParams P) {
 
 // ------------------------------------------------------------------------ wgrad fast path
 // Straight-line loader for the hot case (every operand 16-byte addressable).  A 16-row tile is
-// 640 dZ chunks + 640 X chunks of 16 bytes; thread t owns dZ chunks {t, t+256, t+512 (t<128)}
-// and the same three X chunks, so every slot's role is known at compile time.  Loads are
+// 640 dZ chunks + 16 * (k-block width / 4) X chunks of 16 bytes; thread t owns dZ chunks
+// {t, t+256, t+512 (t<128)} and up to three X chunks, so every slot's role is known at compile time.  Loads are
 // unconditional from (valid ? address : dummy); tail masks, the ReLU mask, the subtraction and
 // the ones column are applied when the registers go to LDS, after the tile's MFMAs.  Gather
 // indices are fetched one tile ahead (row clamped, so the load itself is unconditional); the
 // validity of a gathered row (index >= 0) is latched at issue time.
-template <bool HAS_MASK, bool HAS_SUB>
+template <bool HAS_MASK, bool HAS_SUB, int WTK>
 __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParams P) {
+  // the k extent of the output tile is 32 * WTK columns (160 / 128 / 96): the narrowest one that covers
+  // kext with the given number of k-blocks, so that e.g. k = 361 (+ ones column) costs 3 x 128 instead
+  // of 3 x 160 columns of MFMA work and k = 83 costs 96 instead of 160
+  constexpr int KB = 32 * WTK;                          // columns per k-block
+  constexpr int XC = KB / 4;                            // 16-byte X chunks per row
   __shared__ __attribute__((aligned(16))) float lds[2][2 * WMT * WLD];
   const rr_wgrad_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -737,27 +742,35 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   const int tile = slot % nt, chunk = (slot / nt) * 8 + xcd;
   if (chunk >= P.nchunks) return;
   const int bn = tile / P.nblk_k, bk = tile % P.nblk_k;
-  const int nb = bn * WBN, kb = bk * WBN;
+  const int nb = bn * WBN, kb = bk * KB;
   const int64_t mbeg = static_cast<int64_t>(chunk) * P.rows_per_chunk;
   int64_t mend = mbeg + P.rows_per_chunk;
   if (mend > a.M) mend = a.M;
   const int K = a.k1 + a.k2;
   const float* const dummy = a.dy;
   constexpr int S = 3;                                  // slots per operand per thread
-  const bool slot2 = tid < 640 - 2 * THREADS;           // the third slot exists for t < 128 (waves 0-1)
   const int64_t mlast = a.M - 1;
 
-  int srow[S], scol[S], xkind[S], xcol[S];
+  // dZ: 16 rows x 40 chunks = 640 slots; X: 16 rows x XC chunks (640 / 512 / 384 slots)
+  int zrow[S], zcol[S], xrow[S], xkind[S], xcol[S], xlds[S];
+  bool zuse[S], xuse[S];
 #pragma unroll
   for (int i = 0; i < S; ++i) {
     const int g = tid + i * THREADS;
-    srow[i] = g / 40;
-    scol[i] = (g - srow[i] * 40) * 4;
-    const int k = kb + scol[i];
+    zuse[i] = g < WMT * 40;
+    zrow[i] = zuse[i] ? g / 40 : 0;
+    zcol[i] = zuse[i] ? (g - zrow[i] * 40) * 4 : 0;
+    xuse[i] = g < WMT * XC;
+    xrow[i] = xuse[i] ? g / XC : 0;
+    const int xc0 = xuse[i] ? (g - xrow[i] * XC) * 4 : 0;
+    const int k = kb + xc0;
     xkind[i] = 0;                                       // 1 = segment 1, 2 = segment 2 (+ ones column), 0 = nothing
     xcol[i] = 0;
-    if (k < a.k1) { xkind[i] = 1; xcol[i] = k; }
-    else if (k >= P.k1p && k < P.kext) { xkind[i] = 2; xcol[i] = k - P.k1p; }
+    if (xuse[i]) {
+      if (k < a.k1) { xkind[i] = 1; xcol[i] = k; }
+      else if (k >= P.k1p && k < P.kext) { xkind[i] = 2; xcol[i] = k - P.k1p; }
+    }
+    xlds[i] = xc0;                                      // LDS column of the X chunk inside the k-block
   }
 
   f32x4 zv[S], zm[S], xv[S], xs[S];
@@ -769,7 +782,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   auto fetch_idx = [&](int64_t mt) {
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      int64_t mrow = mt + srow[i];
+      int64_t mrow = mt + xrow[i];
       if (mrow > mlast) mrow = mlast;
       if (a.x1_idx) ia[i] = a.x1_idx[mrow];
       if (HAS_SUB) { if (a.x1_sub_idx) is[i] = a.x1_sub_idx[mrow]; }
@@ -778,12 +791,13 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   auto issue = [&](int64_t mt) {
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      const int64_t mrow = mt + srow[i];
-      const bool rowok = (mrow < mend) && (i < 2 || slot2);
-      const int n = nb + scol[i];
-      const bool zok = rowok && n < a.N;
-      zv[i] = ld4(zok ? a.dy + mrow * a.ld_dy + n : dummy);
-      if (HAS_MASK) zm[i] = ld4(zok ? a.mask + mrow * a.ld_mask + n : dummy);
+      const int64_t mz = mt + zrow[i];
+      const int n = nb + zcol[i];
+      const bool zok = zuse[i] && (mz < mend) && n < a.N;
+      zv[i] = ld4(zok ? a.dy + mz * a.ld_dy + n : dummy);
+      if (HAS_MASK) zm[i] = ld4(zok ? a.mask + mz * a.ld_mask + n : dummy);
+      const int64_t mrow = mt + xrow[i];
+      const bool rowok = xuse[i] && (mrow < mend);
       const float* p = dummy;
       const float* q = dummy;
       bool vx = false, vs = false;
@@ -809,33 +823,41 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   auto commit = [&](int64_t mt, int buf) {
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      if (i == 2 && !slot2) continue;
-      const bool rowok = (mt + srow[i]) < mend;
-      const int n = nb + scol[i];
-      const int xlim = xkind[i] == 1 ? a.k1 : a.k2;
-      f32x4 z, x;
+      if (zuse[i]) {
+        const bool rowok = (mt + zrow[i]) < mend;
+        const int n = nb + zcol[i];
+        f32x4 z;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = (rowok && n + e < a.N) ? zv[i][e] : 0.f;
-        if (HAS_MASK) t = (rowok && n + e < a.N && zm[i][e] > 0.f) ? t * a.mask_scale : 0.f;
-        z[e] = t;
-        float u = (xok[i] && xcol[i] + e < xlim) ? xv[i][e] : 0.f;
-        if (HAS_SUB) u -= (sok[i] && xcol[i] + e < xlim) ? xs[i][e] : 0.f;
-        if (xkind[i] == 2 && rowok && a.k2 - xcol[i] == e) u = 1.0f;   // ones column -> bias gradient
-        x[e] = u;
+        for (int e = 0; e < 4; ++e) {
+          float t = (rowok && n + e < a.N) ? zv[i][e] : 0.f;
+          if (HAS_MASK) t = (rowok && n + e < a.N && zm[i][e] > 0.f) ? t * a.mask_scale : 0.f;
+          z[e] = t;
+        }
+        *reinterpret_cast<f32x4*>(&lds[buf][zrow[i] * WLD + zcol[i]]) = z;
       }
-      *reinterpret_cast<f32x4*>(&lds[buf][srow[i] * WLD + scol[i]]) = z;
-      *reinterpret_cast<f32x4*>(&lds[buf][WMT * WLD + srow[i] * WLD + scol[i]]) = x;
+      if (xuse[i]) {
+        const bool rowok = (mt + xrow[i]) < mend;
+        const int xlim = xkind[i] == 1 ? a.k1 : a.k2;
+        f32x4 x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = (xok[i] && xcol[i] + e < xlim) ? xv[i][e] : 0.f;
+          if (HAS_SUB) u -= (sok[i] && xcol[i] + e < xlim) ? xs[i][e] : 0.f;
+          if (xkind[i] == 2 && rowok && a.k2 - xcol[i] == e) u = 1.0f;   // ones column -> bias gradient
+          x[e] = u;
+        }
+        *reinterpret_cast<f32x4*>(&lds[buf][WMT * WLD + xrow[i] * WLD + xlds[i]]) = x;
+      }
     }
   };
 
-  f32x4 acc[WT][WT];
+  f32x4 acc[WT][WTK];
 #pragma unroll
   for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < WT; ++j) acc[i][j] = f32x4(0.f);
+    for (int j = 0; j < WTK; ++j) acc[i][j] = f32x4(0.f);
 
-  const int wn = (wave >> 1) * (WT * 16), wk = (wave & 1) * (WT * 16);
+  const int wn = (wave >> 1) * (WT * 16), wk = (wave & 1) * (WTK * 16);
   const int fr = lane & 15, fq = lane >> 4;
   const int64_t ntiles = (mend > mbeg) ? (mend - mbeg + WMT - 1) / WMT : 0;
   if (ntiles > 0) {
@@ -856,17 +878,16 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
     const float* Xs = lds[cur] + WMT * WLD;
 #pragma unroll
     for (int kk = 0; kk < WMT / 4; ++kk) {
-      float zf[WT], xf[WT];
+      float zf[WT], xf[WTK];
       const int row = kk * 4 + fq;
 #pragma unroll
-      for (int i = 0; i < WT; ++i) {
-        zf[i] = Zs[row * WLD + wn + i * 16 + fr];
-        xf[i] = Xs[row * WLD + wk + i * 16 + fr];
-      }
+      for (int i = 0; i < WT; ++i) zf[i] = Zs[row * WLD + wn + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < WTK; ++j) xf[j] = Xs[row * WLD + wk + j * 16 + fr];
 #pragma unroll
       for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j)
+        for (int j = 0; j < WTK; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[i], xf[j], acc[i][j], 0, 0, 0);
     }
     if (more) commit(mbeg + (t + 1) * WMT, cur ^ 1);
@@ -877,7 +898,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
 #pragma unroll
-    for (int j = 0; j < WT; ++j) {
+    for (int j = 0; j < WTK; ++j) {
       const int kx = kb + wk + j * 16 + fr;
       if (kx >= P.kext) continue;
       int kreal = -1;
@@ -1078,10 +1099,20 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
   if (a.k2 > 0 && !(P.flags & F_A2_VEC)) fast = false;
   if (a.x1_sub && !(P.flags & F_SUB_VEC)) fast = false;
   if (fast) {
-    if (a.mask && a.x1_sub) wgrad_fast_kernel<true, true><<<grid, THREADS, 0, s>>>(P);
-    else if (a.mask) wgrad_fast_kernel<true, false><<<grid, THREADS, 0, s>>>(P);
-    else if (a.x1_sub) wgrad_fast_kernel<false, true><<<grid, THREADS, 0, s>>>(P);
-    else wgrad_fast_kernel<false, false><<<grid, THREADS, 0, s>>>(P);
+    // narrowest k-block (96 / 128 / 160 columns) that still covers kext with nblk_k blocks
+    const int per_blk = (P.kext + P.nblk_k - 1) / P.nblk_k;
+    const int wtk = per_blk <= 96 ? 3 : (per_blk <= 128 ? 4 : 5);
+#define RR_WGRAD_LAUNCH(MASK, SUB)                                                         \
+    do {                                                                                   \
+      if (wtk == 3) wgrad_fast_kernel<MASK, SUB, 3><<<grid, THREADS, 0, s>>>(P);           \
+      else if (wtk == 4) wgrad_fast_kernel<MASK, SUB, 4><<<grid, THREADS, 0, s>>>(P);      \
+      else wgrad_fast_kernel<MASK, SUB, 5><<<grid, THREADS, 0, s>>>(P);                    \
+    } while (0)
+    if (a.mask && a.x1_sub) RR_WGRAD_LAUNCH(true, true);
+    else if (a.mask) RR_WGRAD_LAUNCH(true, false);
+    else if (a.x1_sub) RR_WGRAD_LAUNCH(false, true);
+    else RR_WGRAD_LAUNCH(false, false);
+#undef RR_WGRAD_LAUNCH
   } else {
     wgrad_kernel<<<grid, THREADS, 0, s>>>(P);
   }
