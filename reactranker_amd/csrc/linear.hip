@@ -490,18 +490,8 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
     }
     if (row_ok && n < a.N) *reinterpret_cast<f32x4*>(crow + n) = v;
   };
-  if (a.c_pre) {                                       // pre-activation side output (W_i layers): plain loop
-    float* prow = a.c_pre + mc * a.ld_pre;
-#pragma unroll
-    for (int tc = 0; tc < NT; ++tc) {
-      const int n = n0 + tc * 16 + nq;
-      f32x4 v = acc[tc];
-      if (has_bias) v = v + *reinterpret_cast<const f32x4*>(bias_s + tc * 16 + nq);
-      if (rrow && n < a.N) v = v + ld4(rrow + n);
-      if (row_ok && n < a.N) *reinterpret_cast<f32x4*>(prow + n) = v;
-      finish(v, n);
-    }
-  } else {
+  float* prow = a.c_pre ? a.c_pre + mc * a.ld_pre : nullptr;   // pre-activation side output (W_i layers)
+  {
     const bool res_ok = rrow != nullptr;
     const float* rbase = res_ok ? rrow : dummy;
     constexpr int D = 4;
@@ -525,6 +515,7 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = res_ok ? vr[e] : v[e];
       if (tc + D < NT) ring[(tc + D) % (D + 1)] = ldres(tc + D);
+      if (prow != nullptr && row_ok && n < a.N) *reinterpret_cast<f32x4*>(prow + n) = v;
       finish(v, n);
     }
   }

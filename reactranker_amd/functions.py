@@ -239,7 +239,12 @@ def _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub,
     A.accumulate = int(accumulate)
     A.workspace, A.workspace_bytes = ptr(ws), nbytes
     # the event pair spans the main kernel and its ~12 us fixed-order reduce kernel
-    key = f"wgrad_fast_kernel<{'true' if mask is not None else 'false'},{'true' if x1_sub is not None else 'false'}>"
+    kext = ((k1 + 3) & ~3) + k2 + 1                     # same k-block choice as rr_linear_wgrad_f32 (96 / 128 / 160 columns)
+    nblk = (kext + 159) // 160
+    per = (kext + nblk - 1) // nblk
+    wtk = 3 if per <= 96 else (4 if per <= 128 else 5)
+    key = (f"wgrad_fast_kernel<{'true' if mask is not None else 'false'},"
+           f"{'true' if x1_sub is not None else 'false'},{wtk}>")
     with _Timed(key, 2 * M * N * (K + 1), 4 * (M * N * (2 if mask is not None else 1) + M * K + N * K)):
         check(lib().rr_linear_wgrad_f32(C.byref(A), stream()), "rr_linear_wgrad_f32")
     return dw
