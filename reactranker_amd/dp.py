@@ -29,7 +29,12 @@ class GradBucket:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        dtype = self.params[0].dtype if self.params else torch.float32      # fp32 in production (fp64 in the CPU identity test)
+        self.flat = torch.zeros(self.numel, dtype=dtype, device=dev)
+        self._views, off = [], 0
+        for p in self.params:
+            self._views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
 
     def allreduce(self, local_weight: float = 1.0, group=None) -> None:
         """grad <- sum_ranks(local_weight_r * grad_r).  With equal shards pass 1/world."""
@@ -39,25 +44,15 @@ class GradBucket:
                     if p.grad is not None:
                         p.grad.mul_(local_weight)
             return
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        # pack: one batched cat kernel (missing grads contribute zeros), one collective, one batched copy back
+        missing = [p for p in self.params if p.grad is None]
+        for p in missing:
+            p.grad = torch.zeros_like(p)
+        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
         if local_weight != 1.0:
             self.flat.mul_(local_weight)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+        torch._foreach_copy_([p.grad for p in self.params], list(self._views))
 
 
 def loss_weight(kind: str, local_queries: int, global_queries: int, local_cands: int, global_cands: int,
