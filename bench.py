@@ -207,15 +207,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the warm-up steps are timed per launch for every heavy kernel, to find the dominant MFMA kernel; the timed
+    # region then carries events around that kernel and the gather kernel only (an event pair around all ~60
+    # heavy launches of a step costs ~4 % of the step)
+    dominant = None
+    if not args.no_profile:
+        Fn.Profiler.start()
     for i in range(args.warmup):
         train_step(i)
     fence()
-    log(f"timing {args.steps} steps")
     if not args.no_profile:
-        Fn.Profiler.start()
+        tot = {}
+        for key, flops, _, e0, e1 in Fn.Profiler.stop():
+            if flops:
+                tot[key] = tot.get(key, 0.0) + e0.elapsed_time(e1)
+        dominant = max(tot, key=tot.get) if tot else None
+    log(f"timing {args.steps} steps (live events on: {dominant}, gather_sum_kernel)")
+    if not args.no_profile:
+        Fn.Profiler.start(only=[k for k in (dominant, "gather_sum_kernel") if k])
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
+        if not args.no_profile:                           # events around the launches of every 5th step only: an event
+            Fn.Profiler.enabled = (i % 5 == 0)            # pair costs ~14 us of stream time (5 % of the step if always on)
         last = train_step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
@@ -294,10 +308,16 @@ def main():
     # timed region: kernels of the three streams overlap, so a kernel's launch duration includes the time it
     # shares the chip with kernels of the other streams (this is what rocprofv3 --stats of this command shows)
     roof, roof_g, ktable = summarise(records)
+    load_clock = {"clock_ghz": 1.8, "peak": round(PEAK_F32_MFMA_TFLOPS * 1.8 / 2.4, 1), "unit": "TFLOP/s",
+                  "source": "shader clock measured inside the k-loop of this kernel under load (s_memtime / s_memrealtime, "
+                            "tools/trace_linear.py, profiles/r01_linear_phase_trace.txt); the datasheet peak assumes 2.4 GHz"}
+    if roof:
+        roof["peak_at_load_clock"] = load_clock
     if roof:
         roof["note"] = "timed region; weight-gradient / reactant-encoder streams run concurrently with the main stream"
     # isolated pass: the same steps with every kernel serialised on one stream -> per-kernel quality
     roof_iso = roof_g_iso = None
+    ktable_iso = {}
     if records:
         side0, aux0 = Fn.SideStream.enabled, Fn.AuxStream.enabled
         Fn.SideStream.enabled = Fn.AuxStream.enabled = False
@@ -309,6 +329,7 @@ def main():
         roof_iso, roof_g_iso, ktable_iso = summarise(Fn.Profiler.stop())
         Fn.SideStream.enabled, Fn.AuxStream.enabled = side0, aux0
         if roof_iso:
+            roof_iso["peak_at_load_clock"] = load_clock
             roof_iso["note"] = "extra pass after the timed region, one stream (kernels do not overlap)"
 
     cpu = None
@@ -335,7 +356,7 @@ def main():
                                       f"gradient bucket per step)"},
             "roofline": roof, "roofline_gather": roof_g, "roofline_isolated": roof_iso,
             "roofline_gather_isolated": roof_g_iso, "cpu_baseline": cpu,
-            "kernels": ktable, "final_loss": round(loss_val, 6),
+            "kernels": ktable, "kernels_isolated": ktable_iso, "final_loss": round(loss_val, 6),
             "host_prep_s": {"synthetic_generation": round(t_gen, 2), "native_pack_and_upload": round(t_pack, 2)},
         }
         line.update(extra)

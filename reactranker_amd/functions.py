@@ -36,10 +36,11 @@ class Profiler:
     stream (bench.py's roofline leg).  Off by default; records (kernel key, work, event pair)."""
     enabled = False
     records = []
+    only = None             # optional set of kernel keys: time just these (keeps the event overhead out of the rest)
 
     @classmethod
-    def start(cls):
-        cls.enabled, cls.records = True, []
+    def start(cls, only=None):
+        cls.enabled, cls.records, cls.only = True, [], (set(only) if only else None)
 
     @classmethod
     def stop(cls):
@@ -49,7 +50,7 @@ class Profiler:
 
 class _Timed:
     def __init__(self, key, flops, nbytes):
-        self.on = Profiler.enabled
+        self.on = Profiler.enabled and (Profiler.only is None or key in Profiler.only)
         if self.on:
             self.key, self.flops, self.nbytes = key, flops, nbytes
             self.e0 = torch.cuda.Event(enable_timing=True)

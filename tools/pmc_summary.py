@@ -5,7 +5,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 first = None
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    m = re.search(r'(linear_fast_kernel<\d+, \d+>|linear_kernel<\d+, \d+>|wgrad_fast_kernel<\w+, \w+>|wgrad_kernel|gather_sum_kernel<\d>|gather_diff_kernel<\d>|relu_bwd_kernel|colsum_\w+_kernel|wgrad_reduce_kernel|segment_\w+|listmle_\w+|pack_weight_kernel)', n)
+    m = re.search(r'(linear_fast_kernel<\d+, \d+>|linear_kernel<\d+, \d+>|wgrad_fast_kernel<\w+, \w+, \d>|wgrad_kernel|gather_sum_kernel<\d>|gather_diff_kernel<\d>|relu_bwd_kernel|colsum_\w+_kernel|wgrad_reduce_kernel|segment_\w+|listmle_\w+|pack_weight_kernel)', n)
     k = m.group(1) if m else n[:40]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     first = first or r["Counter_Name"]
