@@ -159,6 +159,8 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     kk = k1 + k2
     nbytes = 4 * (M * kk * (2 if (a1_sub is not None or a_mask is not None) else 1) + N * kk + M * N *
                   (1 + (residual is not None) + (c_pre is not None)))
+    if dz_out is not None:                              # side output d_input (+)= dZ: one write, one read when accumulating
+        nbytes += 4 * M * k1 * (2 if dz_accumulate else 1)
     kern = "linear_fast_kernel" if w_packed else "linear_kernel"
     with _Timed(f"{kern}<{nt},{mode}>", 2 * M * N * kk, nbytes):
         check(lib().rr_linear_f32(C.byref(A), stream()), "rr_linear_f32")
