@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--no-side-stream", action="store_true", help="run weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="run the reactant encoder on the main stream")
     ap.add_argument("--aux-backward", action="store_true", help="also run the reactant encoder's backward on the aux stream")
+    ap.add_argument("--foreach-adam", action="store_true", help="torch's multi-kernel Adam instead of its fused single-kernel one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,7 +179,8 @@ def main():
                         use_bias=True, dropout=args.dropout, task_num=1, ffn_last_layer="with_softplus",
                         add_features_dim=1).to(device)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0)
+    # the reference builds torch.optim.Adam (train/utils.py:93-106); fused=True is the same update in one kernel
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, fused=not args.foreach_adam)
     bucket = GradBucket(model.parameters())
     mle = RL.MLEloss()
     log("building the step pool (synthetic graphs -> native packer -> HBM)")
