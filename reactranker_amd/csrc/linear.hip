@@ -20,6 +20,7 @@
 // f32 MFMA is bit-for-bit an fmaf chain (no reduced precision anywhere); results differ
 // from the CPU reference only by summation order.
 #include "rr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -708,20 +709,31 @@ __global__ void __launch_bounds__(THREADS) wgrad_kernel(const WgradParams P) {
 
 
 // ------------------------------------------------------------------------ wgrad fast path
-// Straight-line loader for the hot case (every operand 16-byte addressable).  A 16-row tile is
-// 640 dZ chunks + 16 * (k-block width / 4) X chunks of 16 bytes; thread t owns dZ chunks
-// {t, t+256, t+512 (t<128)} and up to three X chunks, so every slot's role is known at compile time.  Loads are
-// unconditional from (valid ? address : dummy); tail masks, the ReLU mask, the subtraction and
-// the ones column are applied when the registers go to LDS, after the tile's MFMAs.  Gather
-// indices are fetched one tile ahead (row clamped, so the load itself is unconditional); the
-// validity of a gathered row (index >= 0) is latched at issue time.
+// Hot case: every operand 16-byte addressable, N % 4 == 0.  A 16-row tile is 640 dZ chunks +
+// 16 * (k-block width / 4) X chunks of 16 bytes; thread t owns dZ chunks {t, t+256, t+512 (t<128)}
+// and up to three X chunks, so every slot's role is known before the loop.
+//
+// The loop is VALU-bound if the loader is written naively (per-tile 64-bit address products,
+// per-element bounds selects: ~500 VALU + ~300 SALU instructions per tile against 100 MFMAs, measured
+// 61 % matrix-pipe duty).  So all per-tile work that can be hoisted is hoisted:
+//  * every streamed operand is a per-slot POINTER that advances by 16 rows per tile (one 64-bit add);
+//  * a slot that must read as zero (column block tail, k-block tail, unused slot) points at a zero
+//    chunk with stride 0 — no validity select in the loop; the ones column (bias gradient) is a
+//    constant {1,0,0,0} chunk when it starts a chunk (k2 % 4 == 0);
+//  * gathered rows cost one v_mad_u64_u32 (index x row pitch + column pointer) and one select
+//    (index < 0 -> zero chunk); indices are fetched one tile ahead from an advancing pointer;
+//  * rows past the end of the M-chunk exist only in its last tile, which takes a separate
+//    instantiation of the issue code (selects to the zero chunk); the steady state has none;
+//  * partial 16-byte chunks (k1 % 4 or k2 % 4 != 0) are patched per element only under a uniform flag.
+// What remains per tile: the loads, the pointer bumps, the ReLU-mask select and the subtraction.
+__device__ __attribute__((aligned(16))) const float rr_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) const float rr_one_chunk[4] = {1.f, 0.f, 0.f, 0.f};
+
 template <bool HAS_MASK, bool HAS_SUB, int WTK>
 __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParams P) {
-  // the k extent of the output tile is 32 * WTK columns (160 / 128 / 96): the narrowest one that covers
-  // kext with the given number of k-blocks, so that e.g. k = 361 (+ ones column) costs 3 x 128 instead
-  // of 3 x 160 columns of MFMA work and k = 83 costs 96 instead of 160
-  constexpr int KB = 32 * WTK;                          // columns per k-block
+  constexpr int KB = 32 * WTK;                          // columns per k-block (160 / 128 / 96)
   constexpr int XC = KB / 4;                            // 16-byte X chunks per row
+  constexpr int S = 3;                                  // slots per operand per thread
   __shared__ __attribute__((aligned(16))) float lds[2][2 * WMT * WLD];
   const rr_wgrad_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -732,112 +744,159 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile = slot % nt, chunk = (slot / nt) * 8 + xcd;
   if (chunk >= P.nchunks) return;
+  RR_STAMP(0);
   const int bn = tile / P.nblk_k, bk = tile % P.nblk_k;
   const int nb = bn * WBN, kb = bk * KB;
   const int64_t mbeg = static_cast<int64_t>(chunk) * P.rows_per_chunk;
   int64_t mend = mbeg + P.rows_per_chunk;
   if (mend > a.M) mend = a.M;
   const int K = a.k1 + a.k2;
-  const float* const dummy = a.dy;
-  constexpr int S = 3;                                  // slots per operand per thread
-  const int64_t mlast = a.M - 1;
+  const int nrows = static_cast<int>(mend - mbeg);      // rows of this M-chunk (> 0: chunk < nchunks)
+  const int ntiles = (nrows + WMT - 1) / WMT;
+  const float* const zero = rr_zero_chunk;
+  const bool partial = (a.k1 & 3) != 0 || (a.k2 & 3) != 0;
 
-  // dZ: 16 rows x 40 chunks = 640 slots; X: 16 rows x XC chunks (640 / 512 / 384 slots)
-  int zrow[S], zcol[S], xrow[S], xkind[S], xcol[S], xlds[S];
-  bool zuse[S], xuse[S];
+  // ---- slot roles (loop invariant)
+  enum : int { X_NONE = 0, X_DIRECT = 1, X_GATHER = 2, X_ONES = 3 };
+  int zrow[S], zoff[S], xrow[S], xoff[S], xkind[S], nval[S], onee[S];
+  const float* pz[S];                                   // dZ chunk of this slot in the current tile (advances)
+  const float* pm[S];                                   // ReLU-mask chunk
+  const float* px[S];                                   // X chunk (direct) or column pointer into row 0 (gather)
+  const float* ps[S];                                   // subtract source, same two forms
+  const int32_t* pi[S];                                 // gather index of the slot's row, one tile ahead
+  const int32_t* pj[S];
+  int64_t zstep[S], mstep[S], xstep[S], sstep[S];       // bytes per tile (0 for constant chunks)
+  bool sgather[S];
 #pragma unroll
   for (int i = 0; i < S; ++i) {
     const int g = tid + i * THREADS;
-    zuse[i] = g < WMT * 40;
-    zrow[i] = zuse[i] ? g / 40 : 0;
-    zcol[i] = zuse[i] ? (g - zrow[i] * 40) * 4 : 0;
-    xuse[i] = g < WMT * XC;
-    xrow[i] = xuse[i] ? g / XC : 0;
-    const int xc0 = xuse[i] ? (g - xrow[i] * XC) * 4 : 0;
-    const int k = kb + xc0;
-    xkind[i] = 0;                                       // 1 = segment 1, 2 = segment 2 (+ ones column), 0 = nothing
-    xcol[i] = 0;
-    if (xuse[i]) {
-      if (k < a.k1) { xkind[i] = 1; xcol[i] = k; }
-      else if (k >= P.k1p && k < P.kext) { xkind[i] = 2; xcol[i] = k - P.k1p; }
+    // dZ
+    const bool zuse = g < WMT * 40;
+    zrow[i] = zuse ? g / 40 : 0;
+    const int zcol = zuse ? (g - zrow[i] * 40) * 4 : 0;
+    zoff[i] = zuse ? zrow[i] * WLD + zcol : -1;
+    const bool zok = zuse && (nb + zcol < a.N);
+    pz[i] = zok ? a.dy + (mbeg + zrow[i]) * a.ld_dy + nb + zcol : zero;
+    zstep[i] = zok ? static_cast<int64_t>(WMT) * a.ld_dy * 4 : 0;
+    pm[i] = zero;
+    mstep[i] = 0;
+    if (HAS_MASK && zok) {
+      pm[i] = a.mask + (mbeg + zrow[i]) * a.ld_mask + nb + zcol;
+      mstep[i] = static_cast<int64_t>(WMT) * a.ld_mask * 4;
     }
-    xlds[i] = xc0;                                      // LDS column of the X chunk inside the k-block
+    // X
+    const bool xuse = g < WMT * XC;
+    xrow[i] = xuse ? g / XC : 0;
+    const int xc0 = xuse ? (g - xrow[i] * XC) * 4 : 0;
+    xoff[i] = xuse ? WMT * WLD + xrow[i] * WLD + xc0 : -1;
+    const int kx = kb + xc0;                            // extended column of the chunk
+    xkind[i] = X_NONE;
+    px[i] = zero; ps[i] = zero; xstep[i] = 0; sstep[i] = 0; sgather[i] = false;
+    pi[i] = nullptr; pj[i] = nullptr;
+    nval[i] = 4; onee[i] = -1;
+    if (xuse && kx < a.k1) {                            // segment 1
+      nval[i] = min(4, a.k1 - kx);
+      if (a.x1_idx) {
+        xkind[i] = X_GATHER;
+        px[i] = a.x1 + kx;
+        pi[i] = a.x1_idx + mbeg + xrow[i];
+      } else {
+        xkind[i] = X_DIRECT;
+        px[i] = a.x1 + (mbeg + xrow[i]) * a.ldx1 + kx;
+        xstep[i] = static_cast<int64_t>(WMT) * a.ldx1 * 4;
+      }
+      if (HAS_SUB) {
+        if (a.x1_sub_idx) {
+          sgather[i] = true;
+          ps[i] = a.x1_sub + kx;
+          pj[i] = a.x1_sub_idx + mbeg + xrow[i];
+        } else {
+          ps[i] = a.x1_sub + (mbeg + xrow[i]) * a.ldx1_sub + kx;
+          sstep[i] = static_cast<int64_t>(WMT) * a.ldx1_sub * 4;
+        }
+      }
+    } else if (xuse && kx >= P.k1p && kx < P.kext) {    // segment 2 and / or the ones column
+      const int c2 = kx - P.k1p;
+      if (c2 < a.k2) {
+        xkind[i] = X_DIRECT;
+        px[i] = a.x2 + (mbeg + xrow[i]) * a.ldx2 + c2;
+        xstep[i] = static_cast<int64_t>(WMT) * a.ldx2 * 4;
+        nval[i] = min(4, a.k2 - c2);
+        if (a.k2 - c2 < 4) onee[i] = a.k2 - c2;         // ones column shares this chunk (k2 % 4 != 0)
+      } else {                                          // c2 == k2 (k2 % 4 == 0): the chunk is {1, 0, 0, 0}
+        xkind[i] = X_ONES;
+        px[i] = rr_one_chunk;
+        nval[i] = 0; onee[i] = 0;
+      }
+    }
   }
 
   f32x4 zv[S], zm[S], xv[S], xs[S];
-  bool xok[S], sok[S];
+  bool xrv[S];                                          // the X slot's row is inside the M-chunk (latched at issue)
   int32_t ia[S], is[S];
 #pragma unroll
-  for (int i = 0; i < S; ++i) { ia[i] = 0; is[i] = 0; }
+  for (int i = 0; i < S; ++i) { ia[i] = 0; is[i] = 0; xrv[i] = true; }
 
-  auto fetch_idx = [&](int64_t mt) {
+  // indices for the tile whose first row is `r0` (relative to mbeg); rows past the chunk read the last row's index
+  auto fetch_idx = [&](int r0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      int64_t mrow = mt + xrow[i];
-      if (mrow > mlast) mrow = mlast;
-      if (a.x1_idx) ia[i] = a.x1_idx[mrow];
-      if (HAS_SUB) { if (a.x1_sub_idx) is[i] = a.x1_sub_idx[mrow]; }
+      const int over = r0 + xrow[i] - (nrows - 1);      // > 0: past the end -> step back to the last row
+      const int back = over > 0 ? over : 0;
+      if (xkind[i] == X_GATHER) ia[i] = pi[i][r0 - back];
+      if (HAS_SUB) { if (sgather[i]) is[i] = pj[i][r0 - back]; }
     }
   };
-  auto issue = [&](int64_t mt) {
+  // LAST = the tile may contain rows past the end of the M-chunk
+  auto issue = [&](auto LASTC, int rows_left) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(LASTC)::value;
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      const int64_t mz = mt + zrow[i];
-      const int n = nb + zcol[i];
-      const bool zok = zuse[i] && (mz < mend) && n < a.N;
-      zv[i] = ld4(zok ? a.dy + mz * a.ld_dy + n : dummy);
-      if (HAS_MASK) zm[i] = ld4(zok ? a.mask + mz * a.ld_mask + n : dummy);
-      const int64_t mrow = mt + xrow[i];
-      const bool rowok = xuse[i] && (mrow < mend);
-      const float* p = dummy;
-      const float* q = dummy;
-      bool vx = false, vs = false;
-      if (xkind[i] == 1) {
-        const int64_t j = a.x1_idx ? static_cast<int64_t>(ia[i]) : mrow;
-        vx = rowok && j >= 0;
-        if (vx) p = a.x1 + j * a.ldx1 + xcol[i];
-        if (HAS_SUB) {
-          const int64_t js = a.x1_sub_idx ? static_cast<int64_t>(is[i]) : mrow;
-          vs = rowok && js >= 0;
-          if (vs) q = a.x1_sub + js * a.ldx1_sub + xcol[i];
-        }
-      } else if (xkind[i] == 2) {
-        vx = rowok && xcol[i] < a.k2;
-        if (vx) p = a.x2 + mrow * a.ldx2 + xcol[i];
+      const bool zr = !LAST || zrow[i] < rows_left;
+      zv[i] = ld4(zr ? pz[i] : zero);
+      if (HAS_MASK) zm[i] = ld4(zr ? pm[i] : zero);
+      pz[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pz[i]) + zstep[i]);
+      if (HAS_MASK) pm[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pm[i]) + mstep[i]);
+      const bool xr = !LAST || xrow[i] < rows_left;
+      xrv[i] = xr;
+      const float* p = px[i];
+      if (xkind[i] == X_GATHER)
+        p = ia[i] >= 0 ? px[i] + static_cast<uint64_t>(static_cast<uint32_t>(ia[i])) * static_cast<uint32_t>(a.ldx1) : zero;
+      xv[i] = ld4(xr ? p : zero);
+      px[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px[i]) + xstep[i]);
+      if (HAS_SUB) {
+        const float* q = ps[i];
+        if (sgather[i])
+          q = is[i] >= 0 ? ps[i] + static_cast<uint64_t>(static_cast<uint32_t>(is[i])) * static_cast<uint32_t>(a.ldx1_sub) : zero;
+        xs[i] = ld4(xr ? q : zero);
+        ps[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ps[i]) + sstep[i]);
       }
-      xok[i] = vx;
-      sok[i] = vs;
-      xv[i] = ld4(p);
-      if (HAS_SUB) xs[i] = ld4(q);
     }
   };
-  auto commit = [&](int64_t mt, int buf) {
+  auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      if (zuse[i]) {
-        const bool rowok = (mt + zrow[i]) < mend;
-        const int n = nb + zcol[i];
-        f32x4 z;
+      if (zoff[i] >= 0) {
+        f32x4 z = zv[i];
+        if (HAS_MASK) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = (rowok && n + e < a.N) ? zv[i][e] : 0.f;
-          if (HAS_MASK) t = (rowok && n + e < a.N && zm[i][e] > 0.f) ? t * a.mask_scale : 0.f;
-          z[e] = t;
+          for (int e = 0; e < 4; ++e) z[e] = zm[i][e] > 0.f ? zv[i][e] * a.mask_scale : 0.f;
         }
-        *reinterpret_cast<f32x4*>(&lds[buf][zrow[i] * WLD + zcol[i]]) = z;
+        *reinterpret_cast<f32x4*>(&lds[buf][zoff[i]]) = z;
       }
-      if (xuse[i]) {
-        const bool rowok = (mt + xrow[i]) < mend;
-        const int xlim = xkind[i] == 1 ? a.k1 : a.k2;
-        f32x4 x;
+      if (xoff[i] >= 0) {
+        f32x4 x = xv[i];
+        if (HAS_SUB) x = xv[i] - xs[i];
+        if (partial) {                                  // k1 % 4 or k2 % 4 != 0: patch the chunk per element
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float u = (xok[i] && xcol[i] + e < xlim) ? xv[i][e] : 0.f;
-          if (HAS_SUB) u -= (sok[i] && xcol[i] + e < xlim) ? xs[i][e] : 0.f;
-          if (xkind[i] == 2 && rowok && a.k2 - xcol[i] == e) u = 1.0f;   // ones column -> bias gradient
-          x[e] = u;
+          for (int e = 0; e < 4; ++e) {
+            float u = e < nval[i] ? xv[i][e] : 0.f;
+            if (HAS_SUB) u -= e < nval[i] ? xs[i][e] : 0.f;
+            if (e == onee[i]) u = xrv[i] ? 1.0f : 0.f;
+            x[e] = u;
+          }
         }
-        *reinterpret_cast<f32x4*>(&lds[buf][WMT * WLD + xrow[i] * WLD + xlds[i]]) = x;
+        *reinterpret_cast<f32x4*>(&lds[buf][xoff[i]]) = x;
       }
     }
   };
@@ -850,21 +909,34 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
 
   const int wn = (wave >> 1) * (WT * 16), wk = (wave & 1) * (WTK * 16);
   const int fr = lane & 15, fq = lane >> 4;
-  const int64_t ntiles = (mend > mbeg) ? (mend - mbeg + WMT - 1) / WMT : 0;
-  if (ntiles > 0) {
-    fetch_idx(mbeg);
-    issue(mbeg);
-    fetch_idx(mbeg + WMT);
-    commit(mbeg, 0);
-  }
+  using TrueC = std::integral_constant<bool, true>;
+  using FalseC = std::integral_constant<bool, false>;
+  // tile 0
+  fetch_idx(0);
+  if (nrows < WMT) issue(TrueC{}, nrows); else issue(FalseC{}, WMT);
+  fetch_idx(WMT);
+  commit(0);
   __syncthreads();
-  for (int64_t t = 0; t < ntiles; ++t) {
-    const int cur = static_cast<int>(t & 1);
+  RR_STAMP(1);
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
     const bool more = t + 1 < ntiles;
+#ifdef RR_TRACE_LOOP
+#define RR_LSTAMP(q)                                                                                      \
+    do {                                                                                                   \
+      if (rr_trace_buf && (threadIdx.x & 63) == 0 && blockIdx.x < 2 && t < 48)                             \
+        rr_trace_buf[4096 * 8 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 48 + t) * 8 + (q)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define RR_LSTAMP(q)
+#endif
+    RR_LSTAMP(0);
     if (more) {
-      issue(mbeg + (t + 1) * WMT);                      // uses the indices fetched one tile ago
-      fetch_idx(mbeg + (t + 2) * WMT);
+      const int left = nrows - (t + 1) * WMT;           // rows of tile t+1 (uses the indices fetched one tile ago)
+      if (left < WMT) issue(TrueC{}, left); else issue(FalseC{}, WMT);
+      fetch_idx((t + 2) * WMT);
     }
+    RR_LSTAMP(1);
     const float* Zs = lds[cur];
     const float* Xs = lds[cur] + WMT * WLD;
 #pragma unroll
@@ -881,10 +953,18 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
         for (int j = 0; j < WTK; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[i], xf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) commit(mbeg + (t + 1) * WMT, cur ^ 1);
+    RR_LSTAMP(2);
+#ifdef RR_TRACE_LOOP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RR_LSTAMP(3);
+#endif
+    if (more) commit(cur ^ 1);
+    RR_LSTAMP(4);
     __syncthreads();
+    RR_LSTAMP(5);
   }
 
+  RR_STAMP(2);
   float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(chunk) * P.slab;
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
@@ -906,6 +986,10 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
       }
     }
   }
+#ifdef RR_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RR_STAMP(3);
+#endif
 }
 
 // fixed-order sum of the chunk slabs into dw / dbias
@@ -937,7 +1021,10 @@ __global__ void __launch_bounds__(THREADS) wgrad_reduce_kernel(const float* __re
 
 int64_t wgrad_want_chunks(int64_t M, int N, int kext) {
   const int tiles = ((N + WBN - 1) / WBN) * ((kext + WBN - 1) / WBN);
-  int64_t want = (512 + tiles - 1) / tiles;       // ~512 workgroups: 2 per CU
+  // at most 512 workgroups (2 per CU): a 513th waits a whole round.  Chunk c runs on XCD c % 8 (XCD-aware
+  // mapping), so the chunk count is a multiple of 8: otherwise some XCDs get one more chunk than their 64 slots hold.
+  int64_t want = 512 / tiles;
+  if (want >= 8) want -= want % 8;
   const int64_t maxc = (M + 63) / 64;
   if (want > maxc) want = maxc;
   if (want < 1) want = 1;
@@ -1084,7 +1171,7 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
   if (vec_ok(a.dy, a.ld_dy)) P.flags |= F_EPI_VEC;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(static_cast<unsigned>(P.nblk_n * P.nblk_k * ((P.nchunks + 7) / 8) * 8));
-  bool fast = (P.flags & F_EPI_VEC) != 0;
+  bool fast = (P.flags & F_EPI_VEC) != 0 && (a.N % 4 == 0) && a.M < (int64_t(1) << 31);
   if (a.mask && !(P.flags & F_MASK_VEC)) fast = false;
   if (a.k1 > 0 && !(P.flags & F_A1_VEC)) fast = false;
   if (a.k2 > 0 && !(P.flags & F_A2_VEC)) fast = false;
