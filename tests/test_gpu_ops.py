@@ -190,18 +190,33 @@ def test_wgrad(M, N, k1, k2):
     close(dw / s, 2 * ref_w / s, tol=4e-5, what="dw accumulate")
 
 
-def test_wgrad_gather_sub_operand():
-    torch.manual_seed(3)
-    nA, nB, H = 150, 290, 300
-    a_msg, msg, dz = torch.randn(nA, H), torch.randn(nB, H), torch.randn(nB, H)
-    b2a = torch.randint(0, nA, (nB,), dtype=torch.int32)
-    b2r = torch.randint(0, nB, (nB,), dtype=torch.int32)
-    X = (a_msg[b2a.long()] - msg[b2r.long()]).double()
-    dw = torch.empty(H, H, device="cuda")
-    Fn.wgrad(nB, H, dz.cuda(), dw, x1=a_msg.cuda(), k1=H, x1_idx=b2a.cuda(), x1_sub=msg.cuda(), x1_sub_idx=b2r.cuda())
-    ref = dz.double().t() @ X
+@pytest.mark.parametrize("gather_a,gather_s,mask", [(True, True, False), (True, True, True), (False, False, True),
+                                                     (False, True, False), (True, False, False)])
+@pytest.mark.parametrize("nB", [290, 17, 4099])
+def test_wgrad_gather_sub_operand(gather_a, gather_s, mask, nB):
+    """x = a[ia] - s[is] in the operand loader: direct / gathered sources, negative indices read as zero rows,
+    row counts that are not a multiple of the 16-row tile."""
+    torch.manual_seed(3 + nB)
+    nA, H = 150, 300
+    src_a = torch.randn(nA if gather_a else nB, H)
+    src_s = torch.randn(nB + 7 if gather_s else nB, H)
+    dz, y = torch.randn(nB, H), torch.relu(torch.randn(nB, H))
+    ia = torch.randint(-1, nA, (nB,), dtype=torch.int32) if gather_a else None
+    isub = torch.randint(-1, nB + 7, (nB,), dtype=torch.int32) if gather_s else None
+
+    def rows(src, idx):
+        if idx is None:
+            return src
+        return torch.where((idx >= 0)[:, None], src[idx.clamp(min=0).long()], torch.zeros(1, H))
+    X = (rows(src_a, ia) - rows(src_s, isub)).double()
+    dzz = (dz * (y > 0) * 1.25 if mask else dz).double()
+    dw = torch.empty(H, H, device="cuda"); db = torch.empty(H, device="cuda")
+    Fn.wgrad(nB, H, dz.cuda(), dw, dbias=db, mask=y.cuda() if mask else None, mask_scale=1.25, x1=src_a.cuda(), k1=H,
+             x1_idx=None if ia is None else ia.cuda(), x1_sub=src_s.cuda(), x1_sub_idx=None if isub is None else isub.cuda())
+    ref = dzz.t() @ X
     s = float(ref.abs().max())
     close(dw / s, ref / s, tol=2e-5, what="dw gather-sub")
+    close(db / s, dzz.sum(0) / s, tol=2e-5, what="db gather-sub")
 
 
 def test_relu_bwd_axpby_head_segment():
