@@ -109,6 +109,30 @@ def test_linear_plain(M, N, K, ldk):
     close(got, a[:, :K].double() @ w.double().t(), what="linear bare")
 
 
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("M,N,K", [(517, 300, 300), (64, 300, 300), (3, 32, 32), (130, 600, 300)])
+def test_linear_residual_gathered_by_index(M, N, K, packed):
+    """residual rows picked through residual_idx (-1 = no residual for that row), with bias + ReLU, on the
+    straight-line (packed W) and the generic kernel."""
+    torch.manual_seed(M + N)
+    nR = 41
+    a = torch.randn(M, K)
+    w = torch.randn(N, K) / K ** 0.5
+    b = torch.randn(N)
+    res = torch.randn(nR, N)
+    ridx = torch.randint(-1, nR, (M,), dtype=torch.int32)
+    r = torch.where((ridx >= 0)[:, None], res[ridx.clamp(min=0).long()], torch.zeros(1, N))
+    ref = torch.relu(a.double() @ w.double().t() + b.double() + r.double())
+    if packed:
+        W = Fn.LinW(w.cuda(), b.cuda())
+        got = Fn.linear(M, N, W.pk(K), w_packed=True, a1=a.cuda(), k1=K, bias=W.b, residual=res.cuda(),
+                        residual_idx=ridx.cuda(), act=Fn.ACT_RELU)
+    else:
+        got = Fn.linear(M, N, w.cuda(), a1=a.cuda(), k1=K, bias=b.cuda(), residual=res.cuda(), residual_idx=ridx.cuda(),
+                        act=Fn.ACT_RELU)
+    close(got, ref, what="residual_idx")
+
+
 @pytest.mark.parametrize("H", [300, 32, 30])
 def test_linear_concat_gather_mask(H):
     torch.manual_seed(H)
