@@ -140,7 +140,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads for the CPU baseline (box share = 16)")
     ap.add_argument("--no-profile", action="store_true", help="skip the live HIP-event kernel timing")
-    ap.add_argument("--fwd-only", action="store_true", help="also time forward+loss alone (reported as extra)")
+    ap.add_argument("--fwd-only", action="store_true", help="(default) also time forward+loss alone, reported as extra")
+    ap.add_argument("--no-fwd-only", action="store_true", help="skip the forward+loss-only measurement")
     ap.add_argument("--no-side-stream", action="store_true", help="run weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="run the reactant encoder on the main stream")
     ap.add_argument("--aux-backward", action="store_true", help="also run the reactant encoder's backward on the aux stream")
@@ -244,7 +245,7 @@ def main():
     elapsed = float(t.item())
 
     extra = {}
-    if args.fwd_only:
+    if not args.no_fwd_only:                              # report fwd+loss and fwd+loss+bwd separately
         model.eval()
         with torch.no_grad():                             # upload the de-duplication maps outside the timed loop
             for b in pool:

@@ -18,7 +18,7 @@ cp $(find $out/prof_stats -name "*domain_stats.csv" | head -1) $out/${tag}_bench
 rm -rf $out/prof_stats
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "[collect] pmc pass $c"
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile > /dev/null 2> $out/${tag}_pmc_$c.err
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile --no-fwd-only > /dev/null 2> $out/${tag}_pmc_$c.err
 done
 cd $root
 python3 tools/traffic_from_pmc.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/${tag}_traffic.json
