@@ -12,7 +12,7 @@ out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 echo "[collect] stats pass"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -- python3 $root/bench.py --no-cpu-baseline > $out/${tag}_stats_bench.json 2> $out/${tag}_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -- python3 $root/bench.py --no-cpu-baseline --no-fwd-only > $out/${tag}_stats_bench.json 2> $out/${tag}_stats.err
 cp $(find $out/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
 cp $(find $out/prof_stats -name "*domain_stats.csv" | head -1) $out/${tag}_bench_domain_stats.csv 2>/dev/null || true
 rm -rf $out/prof_stats
