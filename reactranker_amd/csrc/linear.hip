@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   constexpr int KB = 32 * WTK;                          // columns per k-block (160 / 128 / 96)
   constexpr int XC = KB / 4;                            // 16-byte X chunks per row
   constexpr int S = 3;                                  // slots per operand per thread
-  __shared__ __attribute__((aligned(16))) float lds[2][2 * WMT * WLD];
+  __shared__ __attribute__((aligned(16))) float lds[2][2 * WMT * WLD + 4];   // + one dump chunk for unused staging slots
   const rr_wgrad_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so the
@@ -765,7 +765,8 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   const float* ps[S];                                   // subtract source, same two forms
   const int32_t* pi[S];                                 // gather index of the slot's row, one tile ahead
   const int32_t* pj[S];
-  int64_t zstep[S], mstep[S], xstep[S], sstep[S];       // bytes per tile (0 for constant chunks)
+  int gi[S], gj[S];                                     // -1 for gathered slots (index offset mask), 0 otherwise
+  uint32_t zstep[S], mstep[S], xstep[S], sstep[S];      // bytes per tile (0 for constant chunks); 16 rows * pitch < 4 GiB
   bool sgather[S];
 #pragma unroll
   for (int i = 0; i < S; ++i) {
@@ -774,25 +775,26 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
     const bool zuse = g < WMT * 40;
     zrow[i] = zuse ? g / 40 : 0;
     const int zcol = zuse ? (g - zrow[i] * 40) * 4 : 0;
-    zoff[i] = zuse ? zrow[i] * WLD + zcol : -1;
+    zoff[i] = zuse ? zrow[i] * WLD + zcol : 2 * WMT * WLD;
     const bool zok = zuse && (nb + zcol < a.N);
     pz[i] = zok ? a.dy + (mbeg + zrow[i]) * a.ld_dy + nb + zcol : zero;
-    zstep[i] = zok ? static_cast<int64_t>(WMT) * a.ld_dy * 4 : 0;
+    zstep[i] = zok ? static_cast<uint32_t>(WMT * 4 * a.ld_dy) : 0u;
     pm[i] = zero;
     mstep[i] = 0;
     if (HAS_MASK && zok) {
       pm[i] = a.mask + (mbeg + zrow[i]) * a.ld_mask + nb + zcol;
-      mstep[i] = static_cast<int64_t>(WMT) * a.ld_mask * 4;
+      mstep[i] = static_cast<uint32_t>(WMT * 4 * a.ld_mask);
     }
     // X
     const bool xuse = g < WMT * XC;
     xrow[i] = xuse ? g / XC : 0;
     const int xc0 = xuse ? (g - xrow[i] * XC) * 4 : 0;
-    xoff[i] = xuse ? WMT * WLD + xrow[i] * WLD + xc0 : -1;
+    xoff[i] = xuse ? WMT * WLD + xrow[i] * WLD + xc0 : 2 * WMT * WLD;
     const int kx = kb + xc0;                            // extended column of the chunk
     xkind[i] = X_NONE;
     px[i] = zero; ps[i] = zero; xstep[i] = 0; sstep[i] = 0; sgather[i] = false;
-    pi[i] = nullptr; pj[i] = nullptr;
+    pi[i] = reinterpret_cast<const int32_t*>(rr_zero_chunk); pj[i] = pi[i];   // non-gather slots read index 0
+    gi[i] = 0; gj[i] = 0;
     nval[i] = 4; onee[i] = -1;
     if (xuse && kx < a.k1) {                            // segment 1
       nval[i] = min(4, a.k1 - kx);
@@ -800,19 +802,21 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
         xkind[i] = X_GATHER;
         px[i] = a.x1 + kx;
         pi[i] = a.x1_idx + mbeg + xrow[i];
+        gi[i] = -1;
       } else {
         xkind[i] = X_DIRECT;
         px[i] = a.x1 + (mbeg + xrow[i]) * a.ldx1 + kx;
-        xstep[i] = static_cast<int64_t>(WMT) * a.ldx1 * 4;
+        xstep[i] = static_cast<uint32_t>(WMT * 4 * a.ldx1);
       }
       if (HAS_SUB) {
         if (a.x1_sub_idx) {
           sgather[i] = true;
           ps[i] = a.x1_sub + kx;
           pj[i] = a.x1_sub_idx + mbeg + xrow[i];
+          gj[i] = -1;
         } else {
           ps[i] = a.x1_sub + (mbeg + xrow[i]) * a.ldx1_sub + kx;
-          sstep[i] = static_cast<int64_t>(WMT) * a.ldx1_sub * 4;
+          sstep[i] = static_cast<uint32_t>(WMT * 4 * a.ldx1_sub);
         }
       }
     } else if (xuse && kx >= P.k1p && kx < P.kext) {    // segment 2 and / or the ones column
@@ -820,7 +824,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
       if (c2 < a.k2) {
         xkind[i] = X_DIRECT;
         px[i] = a.x2 + (mbeg + xrow[i]) * a.ldx2 + c2;
-        xstep[i] = static_cast<int64_t>(WMT) * a.ldx2 * 4;
+        xstep[i] = static_cast<uint32_t>(WMT * 4 * a.ldx2);
         nval[i] = min(4, a.k2 - c2);
         if (a.k2 - c2 < 4) onee[i] = a.k2 - c2;         // ones column shares this chunk (k2 % 4 != 0)
       } else {                                          // c2 == k2 (k2 % 4 == 0): the chunk is {1, 0, 0, 0}
@@ -842,33 +846,29 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       const int over = r0 + xrow[i] - (nrows - 1);      // > 0: past the end -> step back to the last row
-      const int back = over > 0 ? over : 0;
-      if (xkind[i] == X_GATHER) ia[i] = pi[i][r0 - back];
-      if (HAS_SUB) { if (sgather[i]) is[i] = pj[i][r0 - back]; }
+      const int off = r0 - (over > 0 ? over : 0);
+      ia[i] = pi[i][off & gi[i]];                       // direct slots always read index 0 (>= 0, adds 0 rows)
+      if (HAS_SUB) is[i] = pj[i][off & gj[i]];
     }
   };
-  // LAST = the tile may contain rows past the end of the M-chunk
-  auto issue = [&](auto LASTC, int rows_left) __attribute__((always_inline)) {
-    constexpr bool LAST = decltype(LASTC)::value;
+  // rows_left < 16 only in the last tile of the M-chunk: those rows read the zero chunk.  No branches: every
+  // load is issued, the pointer is what gets selected (a load under a per-lane branch makes hipcc wait at the join)
+  auto issue = [&](int rows_left) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      const bool zr = !LAST || zrow[i] < rows_left;
+      const bool zr = zrow[i] < rows_left;
       zv[i] = ld4(zr ? pz[i] : zero);
       if (HAS_MASK) zm[i] = ld4(zr ? pm[i] : zero);
       pz[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pz[i]) + zstep[i]);
       if (HAS_MASK) pm[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pm[i]) + mstep[i]);
-      const bool xr = !LAST || xrow[i] < rows_left;
+      const bool xr = xrow[i] < rows_left;
       xrv[i] = xr;
-      const float* p = px[i];
-      if (xkind[i] == X_GATHER)
-        p = ia[i] >= 0 ? px[i] + static_cast<uint64_t>(static_cast<uint32_t>(ia[i])) * static_cast<uint32_t>(a.ldx1) : zero;
-      xv[i] = ld4(xr ? p : zero);
+      const float* p = px[i] + static_cast<uint64_t>(static_cast<uint32_t>(ia[i])) * static_cast<uint32_t>(a.ldx1);
+      xv[i] = ld4((xr && ia[i] >= 0) ? p : zero);
       px[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px[i]) + xstep[i]);
       if (HAS_SUB) {
-        const float* q = ps[i];
-        if (sgather[i])
-          q = is[i] >= 0 ? ps[i] + static_cast<uint64_t>(static_cast<uint32_t>(is[i])) * static_cast<uint32_t>(a.ldx1_sub) : zero;
-        xs[i] = ld4(xr ? q : zero);
+        const float* q = ps[i] + static_cast<uint64_t>(static_cast<uint32_t>(is[i])) * static_cast<uint32_t>(a.ldx1_sub);
+        xs[i] = ld4((xr && is[i] >= 0) ? q : zero);
         ps[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ps[i]) + sstep[i]);
       }
     }
@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
   auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-      if (zoff[i] >= 0) {
+      {
         f32x4 z = zv[i];
         if (HAS_MASK) {
 #pragma unroll
@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
         }
         *reinterpret_cast<f32x4*>(&lds[buf][zoff[i]]) = z;
       }
-      if (xoff[i] >= 0) {
+      {
         f32x4 x = xv[i];
         if (HAS_SUB) x = xv[i] - xs[i];
         if (partial) {                                  // k1 % 4 or k2 % 4 != 0: patch the chunk per element
@@ -909,11 +909,9 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
 
   const int wn = (wave >> 1) * (WT * 16), wk = (wave & 1) * (WTK * 16);
   const int fr = lane & 15, fq = lane >> 4;
-  using TrueC = std::integral_constant<bool, true>;
-  using FalseC = std::integral_constant<bool, false>;
   // tile 0
   fetch_idx(0);
-  if (nrows < WMT) issue(TrueC{}, nrows); else issue(FalseC{}, WMT);
+  issue(nrows);
   fetch_idx(WMT);
   commit(0);
   __syncthreads();
@@ -933,7 +931,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
     RR_LSTAMP(0);
     if (more) {
       const int left = nrows - (t + 1) * WMT;           // rows of tile t+1 (uses the indices fetched one tile ago)
-      if (left < WMT) issue(TrueC{}, left); else issue(FalseC{}, WMT);
+      issue(left);
       fetch_idx((t + 2) * WMT);
     }
     RR_LSTAMP(1);
@@ -1179,6 +1177,9 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(static_cast<unsigned>(P.nblk_n * P.nblk_k * ((P.nchunks + 7) / 8) * 8));
   bool fast = (P.flags & F_EPI_VEC) != 0 && (a.N % 4 == 0) && a.M < (int64_t(1) << 31);
+  const int64_t max_pitch = int64_t(1) << 25;          // 16 rows * pitch * 4 bytes must fit the kernel's 32-bit pointer steps
+  if (a.ld_dy >= max_pitch || a.ld_mask >= max_pitch || a.ldx1 >= max_pitch || a.ldx1_sub >= max_pitch || a.ldx2 >= max_pitch)
+    fast = false;
   if (a.mask && !(P.flags & F_MASK_VEC)) fast = false;
   if (a.k1 > 0 && !(P.flags & F_A1_VEC)) fast = false;
   if (a.k2 > 0 && !(P.flags & F_A2_VEC)) fast = false;
