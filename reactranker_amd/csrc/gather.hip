@@ -23,6 +23,8 @@ __device__ inline void st(float* p, typename Vec<VEC>::T v) {
 }
 
 // out[r] = sum_k src[idx[r,k]]   (idx < 0 skipped)
+__device__ __attribute__((aligned(16))) const float gather_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
 template <int VEC>
 __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict__ src, int64_t ld_src,
                                                          const int32_t* __restrict__ idx, int64_t n_out, int K,
@@ -36,18 +38,19 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
     const int32_t* ir = idx + r * K;
     V acc = V(0.0f);
     int k = 0;
+    // pad entries (index < 0) read a zero chunk: the pointer is selected, the load is unconditional - a load
+    // under a per-lane branch makes the compiler drain outstanding loads at the join
     for (; k + 4 <= K; k += 4) {          // 4 independent row loads in flight
       const int32_t j0 = ir[k], j1 = ir[k + 1], j2 = ir[k + 2], j3 = ir[k + 3];
-      V v0 = V(0.0f), v1 = V(0.0f), v2 = V(0.0f), v3 = V(0.0f);
-      if (j0 >= 0) v0 = ld<VEC>(src + j0 * ld_src + c);
-      if (j1 >= 0) v1 = ld<VEC>(src + j1 * ld_src + c);
-      if (j2 >= 0) v2 = ld<VEC>(src + j2 * ld_src + c);
-      if (j3 >= 0) v3 = ld<VEC>(src + j3 * ld_src + c);
+      const V v0 = ld<VEC>(j0 >= 0 ? src + j0 * ld_src + c : gather_zero);
+      const V v1 = ld<VEC>(j1 >= 0 ? src + j1 * ld_src + c : gather_zero);
+      const V v2 = ld<VEC>(j2 >= 0 ? src + j2 * ld_src + c : gather_zero);
+      const V v3 = ld<VEC>(j3 >= 0 ? src + j3 * ld_src + c : gather_zero);
       acc = (((acc + v0) + v1) + v2) + v3;   // k order, like sum(dim=1)
     }
     for (; k < K; ++k) {
       const int32_t j = ir[k];
-      if (j >= 0) acc = acc + ld<VEC>(src + j * ld_src + c);
+      acc = acc + ld<VEC>(j >= 0 ? src + j * ld_src + c : gather_zero);
     }
     st<VEC>(out + r * ld_out + c, acc);
   }
@@ -67,9 +70,8 @@ __global__ void __launch_bounds__(256) gather_diff_kernel(const float* __restric
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * VEC;
     const int32_t ja = ia[r], jm = im[r];
-    V va = V(0.0f), vm = V(0.0f);
-    if (ja >= 0) va = ld<VEC>(a + ja * ld_a + c);
-    if (jm >= 0) vm = ld<VEC>(m + jm * ld_m + c);
+    const V va = ld<VEC>(ja >= 0 ? a + ja * ld_a + c : gather_zero);      // both row loads in flight together
+    const V vm = ld<VEC>(jm >= 0 ? m + jm * ld_m + c : gather_zero);
     st<VEC>(out + r * ld_out + c, va - vm);
   }
 }
@@ -87,8 +89,7 @@ __global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __rest
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * VEC;
     const int32_t j = idx[r];
-    V v = V(0.0f);
-    if (j >= 0) v = ld<VEC>(src + j * ld_src + c);
+    V v = ld<VEC>(j >= 0 ? src + j * ld_src + c : gather_zero);
     if (thr != 0u) {
       const uint64_t base = static_cast<uint64_t>(r) * static_cast<uint64_t>(H) + static_cast<uint64_t>(c);
       if constexpr (VEC == 4) {
