@@ -288,6 +288,8 @@ __device__ unsigned long long* rr_trace_buf = nullptr;
 #define RR_STAMP(slot)
 #endif
 
+__device__ __attribute__((aligned(16))) const float rr_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+
 // ------------------------------------------------------------------------ fast path
 // Same math as linear_kernel, for the hot case: every A source 16-byte addressable and W in
 // the packed layout of rr_pack_weight_f32 ([N][r16(k1) + r16(k2)], zero padded).  The loader
@@ -325,25 +327,34 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
   const float* rowp1 = nullptr;
   const float* rowp2 = nullptr;
   const float* subp = nullptr;                        // MODE 1: subtract source, MODE 2: mask source
-  if (sm < a.M) {
-    if (a.k1 > 0) {
-      if (a.a1_idx) {
-        const int32_t j = a.a1_idx[sm];
-        if (j >= 0) rowp1 = a.a1 + static_cast<int64_t>(j) * a.lda1;
-      } else {
-        rowp1 = a.a1 + sm * a.lda1;
-      }
-      if (MODE == 1 && a.a1_sub) {
-        if (a.a1_sub_idx) {
-          const int32_t j = a.a1_sub_idx[sm];
-          if (j >= 0) subp = a.a1_sub + static_cast<int64_t>(j) * a.lda1_sub;
+  {
+    // both gather indices are loaded before either is used (one memory round trip, not two): the loads are
+    // unconditional from a selected address, the row pointers are derived afterwards
+    const bool in_m = sm < a.M;
+    const int64_t smc = in_m ? sm : 0;
+    const bool g1 = a.k1 > 0 && a.a1_idx != nullptr;
+    const bool g2 = MODE == 1 && a.k1 > 0 && a.a1_sub != nullptr && a.a1_sub_idx != nullptr;
+    const int32_t* const izero = reinterpret_cast<const int32_t*>(rr_zero_chunk);
+    const int32_t j1 = *(g1 ? a.a1_idx + smc : izero);
+    const int32_t j2 = *(g2 ? a.a1_sub_idx + smc : izero);
+    if (in_m) {
+      if (a.k1 > 0) {
+        if (g1) {
+          if (j1 >= 0) rowp1 = a.a1 + static_cast<int64_t>(j1) * a.lda1;
         } else {
-          subp = a.a1_sub + sm * a.lda1_sub;
+          rowp1 = a.a1 + sm * a.lda1;
         }
+        if (MODE == 1 && a.a1_sub) {
+          if (g2) {
+            if (j2 >= 0) subp = a.a1_sub + static_cast<int64_t>(j2) * a.lda1_sub;
+          } else {
+            subp = a.a1_sub + sm * a.lda1_sub;
+          }
+        }
+        if (MODE == 2) subp = a.a_mask + sm * a.ld_mask;
       }
-      if (MODE == 2) subp = a.a_mask + sm * a.ld_mask;
+      if (a.k2 > 0) rowp2 = a.a2 + sm * a.lda2;
     }
-    if (a.k2 > 0) rowp2 = a.a2 + sm * a.lda2;
   }
   float* dzrow = nullptr;                             // MODE 2 side output: dz_out (+)= masked operand
   if (MODE == 2 && a.dz_out && sm < a.M && blockIdx.y == 0) dzrow = a.dz_out + sm * a.ld_dz;
@@ -726,7 +737,6 @@ __global__ void __launch_bounds__(THREADS) wgrad_kernel(const WgradParams P) {
 //    instantiation of the issue code (selects to the zero chunk); the steady state has none;
 //  * partial 16-byte chunks (k1 % 4 or k2 % 4 != 0) are patched per element only under a uniform flag.
 // What remains per tile: the loads, the pointer bumps, the ReLU-mask select and the subtraction.
-__device__ __attribute__((aligned(16))) const float rr_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
 __device__ __attribute__((aligned(16))) const float rr_one_chunk[4] = {1.f, 0.f, 0.f, 0.f};
 
 template <bool HAS_MASK, bool HAS_SUB, int WTK>
