@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
     const bool zuse = g < WMT * 40;
     zrow[i] = zuse ? g / 40 : 0;
     const int zcol = zuse ? (g - zrow[i] * 40) * 4 : 0;
-    zoff[i] = zuse ? zrow[i] * WLD + zcol : 2 * WMT * WLD;
+    zoff[i] = (zuse ? zrow[i] * WLD + zcol : 2 * WMT * WLD) / 4;      // in 16-byte units: the store is a ds_write_b128
     const bool zok = zuse && (nb + zcol < a.N);
     pz[i] = zok ? a.dy + (mbeg + zrow[i]) * a.ld_dy + nb + zcol : zero;
     zstep[i] = zok ? static_cast<uint32_t>(WMT * 4 * a.ld_dy) : 0u;
@@ -799,7 +799,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
     const bool xuse = g < WMT * XC;
     xrow[i] = xuse ? g / XC : 0;
     const int xc0 = xuse ? (g - xrow[i] * XC) * 4 : 0;
-    xoff[i] = xuse ? WMT * WLD + xrow[i] * WLD + xc0 : 2 * WMT * WLD;
+    xoff[i] = (xuse ? WMT * WLD + xrow[i] * WLD + xc0 : 2 * WMT * WLD) / 4;
     const int kx = kb + xc0;                            // extended column of the chunk
     xkind[i] = X_NONE;
     px[i] = zero; ps[i] = zero; xstep[i] = 0; sstep[i] = 0; sgather[i] = false;
@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
 #pragma unroll
           for (int e = 0; e < 4; ++e) z[e] = zm[i][e] > 0.f ? zv[i][e] * a.mask_scale : 0.f;
         }
-        *reinterpret_cast<f32x4*>(&lds[buf][zoff[i]]) = z;
+        reinterpret_cast<f32x4*>(lds[buf])[zoff[i]] = z;
       }
       {
         f32x4 x = xv[i];
@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
             x[e] = u;
           }
         }
-        *reinterpret_cast<f32x4*>(&lds[buf][xoff[i]]) = x;
+        reinterpret_cast<f32x4*>(lds[buf])[xoff[i]] = x;
       }
     }
   };
