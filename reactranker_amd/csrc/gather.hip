@@ -92,9 +92,10 @@ __global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __rest
     V v = ld<VEC>(j >= 0 ? src + j * ld_src + c : gather_zero);
     if (thr != 0u) {
       const uint64_t base = static_cast<uint64_t>(r) * static_cast<uint64_t>(H) + static_cast<uint64_t>(c);
-      if constexpr (VEC == 4) {
+      if constexpr (VEC == 4) {                       // H % 4 == 0 and c % 4 == 0: one aligned group of the mask stream
+        const uint32_t w = rr_hash_group(seed, base >> 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = rr_keep(seed, base + q, thr) ? v[q] * keep_scale : 0.f;
+        for (int q = 0; q < 4; ++q) v[q] = rr_hash_lane(w, q) >= thr ? v[q] * keep_scale : 0.f;
       } else {
         v = rr_keep(seed, base, thr) ? v * keep_scale : 0.f;
       }

@@ -496,9 +496,11 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
       v.w = fmaxf(v.w, 0.f);
     }
     if (P.drop_thr != 0u) {
+      // N % 4 == 0 and n % 4 == 0 on this path: the 4 elements are one aligned group of the mask stream
       const uint64_t base = static_cast<uint64_t>(m) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
+      const uint32_t w = rr_hash_group(a.drop_seed, base >> 2);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = rr_keep(a.drop_seed, base + e, P.drop_thr) ? v[e] * P.keep_scale : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = rr_hash_lane(w, e) >= P.drop_thr ? v[e] * P.keep_scale : 0.f;
     }
     if (row_ok && n < a.N) *reinterpret_cast<f32x4*>(crow + n) = v;
   };

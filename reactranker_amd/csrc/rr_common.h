@@ -37,9 +37,13 @@ static inline int rr_grid_for(int64_t work_items, int block, int max_blocks = RR
   return static_cast<int>(b);
 }
 
-// Counter-based dropout stream: element `index` of stream `seed` is kept iff
-// hash(seed, index) >= p * 2^32.  32-bit murmur3-style mixing (cheap enough for a GEMM
-// epilogue); oracle/dropout_ref.py restates it bit for bit in numpy.
+// Counter-based dropout stream: element `index` of stream `seed` is kept iff hash(seed, index) >= p * 2^32.
+// The hash is two-level so that a GEMM epilogue, which owns 4 consecutive elements per lane, pays the two
+// murmur3 finaliser rounds once per aligned group of 4 (index >> 2) and one multiply per element:
+//   w = fmix32(fmix32(lo(g) ^ s0) + hi(g) * 0x9E3779B1 + s1),  g = index >> 2
+//   h = (w ^ K[index & 3]) * 0x85EBCA6B;  h ^= h >> 15
+// (v_mul_lo_u32 is quarter rate: the one-level form cost ~20 multiplies per 4 elements, ~15 us per round of a
+// dropout-carrying GEMM; this one costs 9).  oracle/dropout_ref.py restates it bit for bit in numpy.
 __host__ __device__ static inline uint32_t rr_fmix32(uint32_t h) {
   h ^= h >> 16;
   h *= 0x85EBCA6Bu;
@@ -48,12 +52,22 @@ __host__ __device__ static inline uint32_t rr_fmix32(uint32_t h) {
   h ^= h >> 16;
   return h;
 }
-__host__ __device__ static inline uint32_t rr_hash_u32(uint64_t seed, uint64_t index) {
-  const uint32_t lo = static_cast<uint32_t>(index), hi = static_cast<uint32_t>(index >> 32);
+// first level: one word per aligned group of 4 elements
+__host__ __device__ static inline uint32_t rr_hash_group(uint64_t seed, uint64_t group) {
+  const uint32_t lo = static_cast<uint32_t>(group), hi = static_cast<uint32_t>(group >> 32);
   const uint32_t s0 = static_cast<uint32_t>(seed), s1 = static_cast<uint32_t>(seed >> 32);
   uint32_t h = rr_fmix32(lo ^ s0);
   h = rr_fmix32(h + hi * 0x9E3779B1u + s1);
   return h;
+}
+// second level: element e (0..3) of the group
+__host__ __device__ static inline uint32_t rr_hash_lane(uint32_t w, uint32_t e) {
+  uint32_t h = (w ^ (e * 0x9E3779B9u + 0x7F4A7C15u)) * 0x85EBCA6Bu;
+  h ^= h >> 15;
+  return h;
+}
+__host__ __device__ static inline uint32_t rr_hash_u32(uint64_t seed, uint64_t index) {
+  return rr_hash_lane(rr_hash_group(seed, index >> 2), static_cast<uint32_t>(index) & 3u);
 }
 __host__ __device__ static inline uint32_t rr_drop_threshold(float p) {
   double t = static_cast<double>(p) * 4294967296.0;
