@@ -18,6 +18,10 @@ L = _lib.lib()
 def run():
     if mode == "m0":
         Fn.linear(nB, H, W.pk(H), w_packed=True, a1=msg, k1=H, out=out)
+    elif mode == "m1_bare":
+        Fn.linear(nB, H, W.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=b2a, a1_sub=msg, a1_sub_idx=b2r, out=out)
+    elif mode == "m1_noidx":
+        Fn.linear(nB, H, W.pk(H), w_packed=True, a1=msg, k1=H, a1_sub=inp, out=out)
     elif mode == "m0_res":
         Fn.linear(nB, H, W.pk(H), w_packed=True, a1=msg, k1=H, bias=W.b, residual=inp, act=1, out=out)
     else:
