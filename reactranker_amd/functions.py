@@ -13,6 +13,7 @@ Reference sites are cited per function (paths relative to the reference root).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -599,7 +600,9 @@ def ffn_forward(x, layers: List[LinW], p: float, seed: int, head: int):
     return out, (hs, raw)
 
 
-def ffn_backward(layers: List[LinW], p: float, head: int, saved, dout, need_dx: bool = True):
+def ffn_backward(layers: List[LinW], p: float, head: int, saved, dout, need_dx: bool = True, dx_cols: Optional[int] = None):
+    """dx_cols: leading input columns whose gradient the caller needs (the readout part; the appended feature
+    columns are inputs without gradient) - lets the first layer's dX run on the straight-line kernel (N % 4 == 0)."""
     hs, raw = saved
     M = raw.shape[0]
     ks = 1.0 / (1.0 - p)
@@ -619,7 +622,8 @@ def ffn_backward(layers: List[LinW], p: float, head: int, saved, dout, need_dx: 
         wgrad(M, L.w.shape[0], dx, gw, dbias=gb, mask=y, mask_scale=ks, x1=hs[li], k1=L.w.shape[1], side=True)
         grads.append((gw, gb))
         if li > 0 or need_dx:
-            dx = linear(M, L.w.shape[1], L.pk_t(0, L.w.shape[1]), w_packed=True, a1=dx, k1=L.w.shape[0], a_mask=y, mask_scale=ks)
+            nin = L.w.shape[1] if (li > 0 or dx_cols is None) else dx_cols
+            dx = linear(M, nin, L.pk_t(0, nin), w_packed=True, a1=dx, k1=L.w.shape[0], a_mask=y, mask_scale=ks)
     grads.reverse()
     return dx, grads
 
@@ -713,7 +717,7 @@ class ReactionModelFn(torch.autograd.Function):
         H, p, seed = st["H"], st["p"], st["seed"]
         rg, pg = st["r"], st["p_graph"]
         dout = _rowmajor(dout.reshape(f_saved[1].shape), "grad_output")
-        dvecs, fg = ffn_backward(ffn, p, st["head"], f_saved, dout, need_dx=True)
+        dvecs, fg = ffn_backward(ffn, p, st["head"], f_saved, dout, need_dx=True, dx_cols=(H if len(ffn) > 1 else None))
         dd = st.get("dedup")
         d_diff, gWi, gbi, gWh, gbh, gWo, gbo = mpndiff_backward(pg, H, st["diff_depth"], dif[0], dif[1], dif[2], p,
                                                                  d_saved, p_h, r_h, dvecs, st["F"], p,
