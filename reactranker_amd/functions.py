@@ -13,7 +13,6 @@ Reference sites are cited per function (paths relative to the reference root).
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import List, Optional
 
 import torch
