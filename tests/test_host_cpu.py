@@ -125,6 +125,28 @@ def test_dropout_stream_host_matches_numpy_restatement():
     assert abs(big.mean() - 0.9) < 5e-3
 
 
+def test_dropout_stream_statistics():
+    """The two-level stream (one hash per aligned group of 4 elements + one multiply per element) must still look
+    like independent Bernoulli draws: keep rate per lane, no correlation inside a group, across groups or seeds."""
+    n = 1 << 20
+    idx = np.arange(n, dtype=np.uint64)
+    for p in (0.1, 0.2, 0.5):
+        k = dropout_ref.keep_mask(12345, idx, p).astype(np.float64)
+        sd = (p * (1 - p) / (n / 4)) ** 0.5
+        for lane in range(4):                                          # each lane of the group on its own
+            assert abs(k[lane::4].mean() - (1 - p)) < 5 * sd
+        g = k.reshape(-1, 4) - (1 - p)
+        for a in range(4):
+            for b in range(a + 1, 4):                                  # lanes of one group are uncorrelated
+                corr = (g[:, a] * g[:, b]).mean() / (p * (1 - p))
+                assert abs(corr) < 5 / (n / 4) ** 0.5
+        corr = ((k[:-4] - (1 - p)) * (k[4:] - (1 - p))).mean() / (p * (1 - p))   # neighbouring groups
+        assert abs(corr) < 5 / n ** 0.5
+        k2 = dropout_ref.keep_mask(12346, idx, p).astype(np.float64)             # neighbouring seeds
+        corr = ((k - (1 - p)) * (k2 - (1 - p))).mean() / (p * (1 - p))
+        assert abs(corr) < 5 / n ** 0.5
+
+
 def test_module_surface_matches_reference_state_dict():
     cfgs = [dict(hidden_size=300, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
                  add_features_dim=1),
