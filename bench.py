@@ -42,14 +42,6 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def noam_lr(step, warmup_steps, total_steps, init_lr, max_lr, final_lr):
-    """NoamLR schedule of the reference trainer (train/utils.py:7-91): linear warm-up, exp decay."""
-    if step <= warmup_steps:
-        return init_lr + step * (max_lr - init_lr) / max(1, warmup_steps)
-    gamma = (final_lr / max_lr) ** (1.0 / max(1, total_steps - warmup_steps))
-    return max_lr * gamma ** (step - warmup_steps)
-
-
 def build_pool(args, rank, device):
     from reactranker_amd import featurization, synth
     pool = []
@@ -180,14 +172,17 @@ def main():
                         use_bias=True, dropout=args.dropout, task_num=1, ffn_last_layer="with_softplus",
                         add_features_dim=1).to(device)
     model.train()
-    # the reference builds torch.optim.Adam (train/utils.py:93-106); fused=True is the same update in one kernel
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, fused=not args.foreach_adam)
+    # the reference's build_optimizer / NoamLR (train/utils.py) through their mirrors; fused Adam = same update, one kernel
+    from reactranker_amd.train_utils import build_lr_scheduler, build_optimizer
+    opt = build_optimizer(model, fused=not args.foreach_adam)
     bucket = GradBucket(model.parameters())
     mle = RL.MLEloss()
     log("building the step pool (synthetic graphs -> native packer -> HBM)")
     pool, t_gen, t_pack = build_pool(args, rank, device)
     log(f"pool ready: {len(pool)} steps, gen {t_gen:.1f}s pack+upload {t_pack:.1f}s; warmup")
-    total_sched = 1563
+    # 100k queries / 64 per step = 1562 steps per epoch; 2 warm-up epochs of 25 (main.py defaults: 1e-4 -> 1e-3 -> 1e-4)
+    sched = build_lr_scheduler(opt, warmup_epochs=2, total_epochs=25, train_data_size=100000,
+                               batch_size=args.queries_per_step, init_lr=1e-4, max_lr=1e-3, final_lr=1e-4)
 
     state = dict(step=0)
 
@@ -199,8 +194,7 @@ def main():
         loss.sum().backward()
         bucket.allreduce(1.0 / world)                     # equal shards: mean of per-rank query-mean grads
         state["step"] += 1
-        lr = noam_lr(state["step"], 2 * 25, total_sched, 1e-4, 1e-3, 1e-4)
-        opt.param_groups[0]["lr"] = lr                    # reference NoamLR writes param_groups[0] (train/utils.py:81)
+        sched.step()                                      # NoamLR writes param_groups[0]['lr'] (train/utils.py:88)
         opt.step()
         return loss
 

@@ -1,0 +1,115 @@
+"""Listwise training loop on pre-packed batches: the loop body, loss dispatch, validation and checkpoint selection
+of the reference trainer (reactranker/train/train_listwise.py:21-372) for the task types whose losses exist in
+reactranker_amd.loss.  The reference's DataFrame / SMILES plumbing (DataProcessor, Parsing_features: out of scope,
+SURVEY.md section 2 row 17) is replaced by an iterable of batches; everything downstream of
+`model(r_inputs, p_inputs, gpu=gpu, add_features=...)` keeps the reference's call shapes.
+
+A batch is a mapping with keys  r, p (BatchMolGraph), scope (list[int]), targets (float32 [M]), add (ndarray [M,F] or
+None) - what train_listwise.py:176-189 gets from generate_batch_reactions + parsing_reactions.
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, List, Optional, Sequence, Union
+
+import torch
+
+from . import loss as RL
+from .eval import ranking_metrics
+from .utils import save_checkpoint
+
+NDCG_METRICS = ["NDCG@1", "NDCG@2", "NDCG@25%", "NDCG@all"]
+SUPPORTED_TASKS = ("mle", "listnet", "evidential_ranking", "gauss_regression", "mle_gaussian", "listnet_gauss",
+                   "mle_regression", "listnet_regression", "regression")
+
+
+def batch_loss(task_type: str, output, scope, targets, gpu, epoch: int = 0, epochs: int = 1, max_coeff: float = 1e-4):
+    """The loss the reference trainer forms for one batch (train_listwise.py:196-285)."""
+    mle, listnet, evid, gauss, mse = RL.MLEloss(), RL.ListnetLoss(), RL.evidential_ranking(), RL.GaussDisLoss(), RL.MSELoss()
+    if task_type == "mle":
+        return mle(output, scope, targets, gpu)
+    if task_type == "listnet":
+        return listnet(output, scope, targets, gpu)
+    if task_type == "evidential_ranking":
+        return evid(output, scope, targets, max_coeff, epoch, epochs, gpu)
+    if task_type == "gauss_regression":
+        return gauss(output[:, 0], output[:, 1], targets, gpu)
+    if task_type == "mle_gaussian":
+        return mle(output[:, 0], scope, targets, gpu) + gauss(output[:, 0], output[:, 1], targets, gpu)
+    if task_type == "listnet_gauss":
+        return listnet(output[:, 0], scope, targets, gpu) + gauss(output[:, 0], output[:, 1], targets, gpu)
+    if task_type == "mle_regression":
+        return mse(output, targets) + mle(output, scope, targets, gpu)
+    if task_type == "listnet_regression":
+        return listnet(output, scope, targets, gpu) + mse(output, targets)
+    if task_type == "regression":                       # the reference's default branch: nn.MSELoss
+        return mse(output, targets)
+    raise ValueError(f"task_type {task_type!r} is not covered by reactranker_amd (supported: {SUPPORTED_TASKS})")
+
+
+def train(model: torch.nn.Module, scheduler, train_batches: Union[Sequence, Callable[[int], Iterable]],
+          val_batches: Sequence, path_checkpoints: Union[str, List[str], None], optimizer, epochs: int, seed: int, gpu: int,
+          task_type: str = "mle", logger=None, save_metric: Optional[str] = None, max_coeff: float = 1e-4,
+          mean: float = 0.0, std: float = 1.0):
+    """Same control flow as the reference train(): fixed seed, per batch forward / loss / zero_grad / backward /
+    optimizer.step / scheduler.step (train_listwise.py:287-290), validation with ranking_metrics after every epoch,
+    checkpoint whenever the selected metric does not get worse (:310-350).  `train_batches` is a sequence, or a
+    callable epoch -> iterable (the reference reshuffles with seed=epoch, :178).  Returns the per-epoch history."""
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    model = model.cuda(gpu)
+    if hasattr(model, "dropout_seed"):
+        model.dropout_seed = seed
+    score_old = [0.0, 0.0, 0.0] if save_metric == "all" else 0.0
+    history = []
+    say = logger.info if logger is not None else (lambda *_: None)
+    for epoch in range(epochs):
+        say("learning rate is: {}".format(optimizer.param_groups[0]["lr"]))
+        model.train()
+        loss = torch.zeros(1)
+        for b in (train_batches(epoch) if callable(train_batches) else train_batches):
+            output = model(b["r"], b["p"], gpu=gpu, add_features=b.get("add"))
+            loss = batch_loss(task_type, output, b["scope"], b["targets"], gpu, epoch, epochs, max_coeff)
+            optimizer.zero_grad()
+            loss.sum().backward()
+            optimizer.step()
+            scheduler.step()
+        model.eval()
+        top1, recall25, top25, ndcg = ranking_metrics(
+            model, gpu, [(b["r"], b["p"], b["scope"], b["targets"], b.get("add")) for b in val_batches])
+        saved = False
+
+        def keep(path):
+            nonlocal saved
+            if path is not None:
+                save_checkpoint(path, model, mean, std)
+                saved = True
+        if save_metric is None or save_metric == "average_score":
+            if top1 >= score_old:
+                score_old = top1
+                keep(path_checkpoints)
+        elif save_metric == "all":
+            for i, v in enumerate((top1, recall25, top25)):
+                if v >= score_old[i]:
+                    score_old[i] = v
+                    keep(path_checkpoints[i] if path_checkpoints is not None else None)
+        elif save_metric == "average_pred_in_targ":
+            if recall25 >= score_old:
+                score_old = recall25
+                keep(path_checkpoints)
+        elif save_metric == "average_top1_in_pred":
+            if top25 >= score_old:
+                score_old = top25
+                keep(path_checkpoints)
+        elif save_metric in NDCG_METRICS:
+            v = ndcg[NDCG_METRICS.index(save_metric)]
+            if v >= score_old:
+                score_old = v
+                keep(path_checkpoints)
+        else:
+            raise Exception("Unknown save metric")
+        rec = dict(epoch=epoch + 1, train_loss=float(loss.detach().sum()), top1=float(top1), top1_in_pred_top25=float(top25),
+                   pred_top25_in_targ_top25=float(recall25), ndcg=[float(x) for x in ndcg], checkpoint=saved)
+        history.append(rec)
+        say("Epoch [{}/{}], train_loss,{:.4f}, top1,{:.4f}, top1_in_pred_top25%,{:.4f}, pred_top25%_in_targ_top25%,{:.4f}"
+            .format(epoch + 1, epochs, rec["train_loss"], top1, top25, recall25))
+    return history

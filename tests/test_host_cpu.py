@@ -197,3 +197,30 @@ def test_unique_maps_are_consistent():
         for u in range(tt.shape[0]):
             rows = tt[u][tt[u] >= 0]
             assert np.array_equal(np.sort(rows), np.flatnonzero(mp == u))
+
+
+def test_train_utils_match_reference_scheduler(golden_dir):
+    """NoamLR / build_optimizer / build_lr_scheduler against the learning rates the reference classes produced."""
+    import json
+    from reactranker_amd import train_utils as TU
+    z = np.load(os.path.join(golden_dir, "train_utils.npz"))
+    i = 0
+    while f"c{i}.cfg" in z:
+        c = json.loads(str(z[f"c{i}.cfg"]))
+        net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 1))
+        opt = TU.build_optimizer(net)
+        g = opt.param_groups[0]
+        assert g["weight_decay"] == 0 and g["betas"] == (0.9, 0.999) and g["eps"] == 1e-8
+        sch = TU.build_lr_scheduler(opt, **c)
+        assert sch.warmup_steps == int(z[f"c{i}.warmup_steps"]) and sch.total_steps == int(z[f"c{i}.total_steps"])
+        want = z[f"c{i}.lrs"]
+        got = [opt.param_groups[0]["lr"]]
+        for _ in range(len(want) - 1):
+            sch.step()
+            got.append(opt.param_groups[0]["lr"])
+        assert np.allclose(got, want, rtol=1e-12, atol=0), (i, np.abs(np.asarray(got) - want).max())
+        sch.step(current_step=7)
+        assert np.isclose(opt.param_groups[0]["lr"], float(z[f"c{i}.jump7"]), rtol=1e-12)
+        assert TU.param_count(net) == int(z[f"c{i}.param_count"])
+        i += 1
+    assert i == 3

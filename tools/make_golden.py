@@ -468,12 +468,51 @@ def gen_eval_metrics():
     print("wrote eval_metrics.npz", {k: v for k, v in out.items() if k.endswith((".top1", ".recall25", ".top25"))})
 
 
+def gen_train_utils():
+    """Learning-rate schedule and optimizer defaults of reactranker/train/utils.py (NoamLR, build_optimizer,
+    build_lr_scheduler), produced by the reference classes themselves."""
+    from reactranker.train.utils import build_lr_scheduler, build_optimizer, param_count
+    out = {}
+    cfgs = [dict(warmup_epochs=2, total_epochs=10, train_data_size=1000, batch_size=50, init_lr=1e-4, max_lr=1e-3,
+                 final_lr=1e-4),
+            dict(warmup_epochs=2.0, total_epochs=25, train_data_size=100000, batch_size=64, init_lr=1e-4, max_lr=1e-3,
+                 final_lr=1e-4),
+            dict(warmup_epochs=1, total_epochs=3, train_data_size=37, batch_size=5, init_lr=5e-5, max_lr=2e-3,
+                 final_lr=1e-5)]
+    for i, c in enumerate(cfgs):
+        net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 1))
+        opt = build_optimizer(net)
+        sch = build_lr_scheduler(opt, **c)
+        total = int(c["total_epochs"] * (c["train_data_size"] // c["batch_size"]))
+        n = min(total + 5, 400)                          # past the end as well (lr stays at final_lr)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(n):
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        sch.step(current_step=7)
+        out[f"c{i}.cfg"] = np.array(json.dumps(c))
+        out[f"c{i}.lrs"] = np.asarray(lrs, np.float64)
+        out[f"c{i}.jump7"] = np.float64(opt.param_groups[0]["lr"])
+        out[f"c{i}.warmup_steps"] = np.int64(sch.warmup_steps)
+        out[f"c{i}.total_steps"] = np.int64(sch.total_steps)
+        g = opt.param_groups[0]
+        out[f"c{i}.adam"] = np.asarray([g["lr"] if False else 1e-4, g["weight_decay"], g["betas"][0], g["betas"][1], g["eps"]],
+                                       np.float64)
+        out[f"c{i}.param_count"] = np.int64(param_count(net))
+    np.savez_compressed(os.path.join(OUT, "train_utils.npz"), **out)
+    print("wrote train_utils.npz", [float(out["c0.lrs"][k]) for k in (0, 1, 40, 41, 200)])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":      # e.g. --only train_utils
+        globals()["gen_" + sys.argv[2]]()
+        sys.exit(0)
     for case in MODEL_CASES:
         gen_model_case(case)
     gen_losses()
     gen_metrics()
     gen_eval_metrics()
+    gen_train_utils()
