@@ -500,3 +500,41 @@ def test_listwise_driver_runs_like_the_reference_trainer(tmp_path, task_type, ta
     b = batches[0]
     out = m2(b["r"], b["p"], 0, b["add"])
     assert torch.isfinite(out).all()
+
+
+def test_ranknet_training_loop_both_algorithms():
+    """reactranker_amd.train_pairwise.factorized_training_loop: 'sum_session' and 'accelerate_grad' step the same model
+    the way the reference loop does (train_pairwise.py:81-173); the lambda form's gradient is half the autograd form's
+    (the reference counts every unordered pair twice in the loss but once in the lambdas)."""
+    from reactranker_amd import train_pairwise as TP, train_utils as TU
+    cfg = dict(hidden_size=64, mpnn_depth=2, mpnn_diff_depth=2, ffn_depth=2, use_bias=True, task_num=1,
+               ffn_last_layer="no_softplus", add_features_dim=0)
+    batches = []
+    for i in range(3):
+        qb = synth.make_queries(900 + i, 6, 12, atoms_lo=6, atoms_hi=10)
+        batches.append(dict(r=featurization.BatchMolGraph(qb.r_specs, K=4), p=featurization.BatchMolGraph(qb.p_specs, K=4),
+                            scope=qb.scope, targets=torch.tensor(qb.targets.astype(np.float32)), add=None))
+    grads = {}
+    for algo in ("sum_session", "accelerate_grad"):
+        torch.manual_seed(1)
+        model = build_model(dropout=0.0, **cfg).cuda()
+        b = batches[0]
+        y = model(b["r"], b["p"], gpu=0, add_features=None)
+        if algo == "sum_session":
+            ls, pairs = RL.ranknet_loss(y, b["scope"], b["targets"], 1.0, 0)
+            (ls / pairs).sum().backward()
+        else:
+            _, pairs = RL.ranknet_loss(y.detach(), b["scope"], b["targets"], 1.0, 0)
+            y.backward(RL.ranknet_lambda(y, b["scope"], b["targets"], 1.0, 0) / pairs)
+        grads[algo] = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]).clone()
+    ratio = float((grads["sum_session"] * grads["accelerate_grad"]).sum() / (grads["accelerate_grad"] ** 2).sum())
+    assert abs(ratio - 2.0) < 1e-3, ratio
+    for algo in ("sum_session", "accelerate_grad"):
+        torch.manual_seed(1)
+        model = build_model(dropout=0.0, **cfg).cuda()
+        opt = TU.build_optimizer(model)
+        sch = TU.build_lr_scheduler(opt, warmup_epochs=1, total_epochs=4, train_data_size=3, batch_size=1, init_lr=1e-3,
+                                    max_lr=3e-3, final_lr=1e-3)
+        losses = [TP.factorized_training_loop(ep, model, opt, sch, batches, 1.0, algo, gpu=0) for ep in range(4)]
+        assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0], (algo, losses)
+        assert sch.current_step == 1 + 4 * len(batches)
