@@ -312,6 +312,9 @@ def test_full_step_size_properties():
 
 
 @pytest.mark.parametrize("name,cfg,scope,loss_kind", [
+    ("cfg1_regression_h300_c10", dict(hidden_size=300, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True,
+                                      task_num=1, ffn_last_layer="no_softplus", task_type=None, add_features_dim=1),
+     [10, 10, 10, 10, 10, 10], "mse"),
     ("cfg2_listnet_h300_c32", dict(hidden_size=300, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True,
                                    task_num=1, ffn_last_layer="with_softplus", task_type=None, add_features_dim=1),
      [32, 32, 32], "listnet"),
@@ -323,8 +326,9 @@ def test_full_step_size_properties():
                                      add_features_dim=1), [9, 16, 5], "evidential"),
 ])
 def test_baseline_configs_against_oracle(name, cfg, scope, loss_kind):
-    """The other BASELINE.json configurations (ListNet 32-candidate lists; RankNet over 64-candidate lists;
-    UC-Listwise with hidden 600 / depth 6) at oracle-sized batches: scores, loss and every gradient."""
+    """The other BASELINE.json configurations (pointwise regression / MSE over 10-candidate queries; ListNet
+    32-candidate lists; RankNet over 64-candidate lists; UC-Listwise with hidden 600 / depth 6) at oracle-sized
+    batches: scores, loss and every gradient."""
     H = cfg["hidden_size"]
     shapes = O.model_shapes(H, cfg["mpnn_depth"], cfg["mpnn_diff_depth"], cfg["ffn_depth"], cfg["task_num"],
                             cfg["add_features_dim"], cfg["use_bias"])
@@ -339,7 +343,9 @@ def test_baseline_configs_against_oracle(name, cfg, scope, loss_kind):
     ref = O.reaction_forward(P, mc, O.pack_batch(qb.r_specs, K=4), O.pack_batch(qb.p_specs, K=4), qb.add_features)
     out = model(rb, pb, gpu=0, add_features=qb.add_features)
     close(out, ref, tol=2e-5 if H == 600 else 1e-5, what=name + " out")
-    if loss_kind == "listnet":
+    if loss_kind == "mse":                                # BASELINE configs[0]: the pointwise 'regression' branch
+        l, l_ref = RL.MSELoss()(out, targets), O.mse_loss(ref, targets)
+    elif loss_kind == "listnet":
         l, l_ref = RL.ListnetLoss()(out, scope, targets, 0), O.listnet_loss(ref, scope, targets)
     elif loss_kind == "evidential":
         l, l_ref = RL.evidential_ranking()(out, scope, targets, None, None, None, 0), \
@@ -361,7 +367,9 @@ def test_baseline_configs_against_oracle(name, cfg, scope, loss_kind):
         return g
     ref64 = O.reaction_forward(P64, mc, g64(qb.r_specs), g64(qb.p_specs), torch.tensor(qb.add_features).double())
     t64 = targets.double()
-    if loss_kind == "listnet":
+    if loss_kind == "mse":
+        l64 = O.mse_loss(ref64, t64)
+    elif loss_kind == "listnet":
         l64 = O.listnet_loss(ref64, scope, t64)
     elif loss_kind == "evidential":
         l64 = O.evidential_ranking_loss(ref64, scope, t64)
