@@ -472,7 +472,8 @@ def test_training_loop_plumbing_loss_decreases_and_checkpoint_resumes(tmp_path):
     assert torch.equal(m2(r, p, 0, a), model(r, p, 0, a))
 
 
-@pytest.mark.parametrize("task_type,task_num,save_metric", [("mle", 1, None), ("listnet_regression", 1, "NDCG@all"),
+@pytest.mark.parametrize("task_type,task_num,save_metric", [("regression", 1, "average_top1_in_pred"),   # BASELINE configs[0]
+                                                            ("mle", 1, None), ("listnet_regression", 1, "NDCG@all"),
                                                             ("evidential_ranking", 2, "average_pred_in_targ")])
 def test_listwise_driver_runs_like_the_reference_trainer(tmp_path, task_type, task_num, save_metric):
     """reactranker_amd.train_listwise.train - the reference trainer's loop (train_listwise.py:176-350) on pre-packed
