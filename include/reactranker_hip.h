@@ -56,6 +56,14 @@ int rr_gather_sum_f32(const float* src, int64_t n_src, int64_t ld_src,
                       const int32_t* idx, int64_t n_out, int K, int H,
                       float* out, int64_t ld_out, rr_stream_t stream);
 
+/* out[r, 0:H] = sum_{j in [offsets[r], offsets[r+1])} src[idx[j], 0:H]   (CSR form, offsets has n_out+1 entries)
+ * The adjoint of index_select_ND (utils.py:176-193) for a GENERIC index tensor: autograd's index_select
+ * backward is a scatter-add; here the sources of every destination row are listed (sorted by destination, stable)
+ * and summed in that fixed order - no atomics, and no pad width to learn with a device->host sync. */
+int rr_gather_sum_csr_f32(const float* src, int64_t n_src, int64_t ld_src,
+                          const int32_t* offsets, const int32_t* idx, int64_t n_out, int H,
+                          float* out, int64_t ld_out, rr_stream_t stream);
+
 /* out[r] = (ia[r] >= 0 ? a[ia[r]] : 0) - (im[r] >= 0 ? m[im[r]] : 0)
  * Replaces  message = a_message[b2a] - message[b2revb]  (models/mpn.py:91-92); with the
  * transposed tables (b2t, b2revb) it is that line's backward. */

@@ -111,6 +111,7 @@ class ReactionModel(nn.Module):
                 dedup = (ub.device_graph(pg.device), cache[1], cache[2])
         prefix = None
         if (dedup is None and self.dedup_reactants in ("auto", True) and p_active > 0.0 and self.encoder.depth >= 2
+                and self.encoder.hidden_size % 4 == 0            # the shared-prefix backward needs the fused dZ side output
                 and hasattr(r_inputs, "unique_bonds")):
             # train mode with dropout: only the deterministic prefix of the reactant encoder (up to its first
             # dropout) is shared across the copies — exact, the per-copy mask stream is unchanged

@@ -56,6 +56,32 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
   }
 }
 
+// out[r] = sum_{j in [offs[r], offs[r+1])} src[idx[j]]  (CSR form: rows with arbitrarily many sources - the adjoint of a
+// gather through a GENERIC index table, where no pad width is known without a device->host sync)
+template <int VEC>
+__global__ void __launch_bounds__(256) gather_sum_csr_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                             const int32_t* __restrict__ offs,
+                                                             const int32_t* __restrict__ idx, int64_t n_out, int HV,
+                                                             float* __restrict__ out, int64_t ld_out) {
+  using V = typename Vec<VEC>::T;
+  const int64_t total = n_out * HV;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / HV;
+    const int c = static_cast<int>(e - r * HV) * VEC;
+    const int32_t beg = offs[r], end = offs[r + 1];
+    V acc = V(0.0f);
+    int32_t j = beg;
+    for (; j + 2 <= end; j += 2) {        // two independent row loads in flight, summed in table order
+      const V v0 = ld<VEC>(src + static_cast<int64_t>(idx[j]) * ld_src + c);
+      const V v1 = ld<VEC>(src + static_cast<int64_t>(idx[j + 1]) * ld_src + c);
+      acc = (acc + v0) + v1;
+    }
+    if (j < end) acc = acc + ld<VEC>(src + static_cast<int64_t>(idx[j]) * ld_src + c);
+    st<VEC>(out + r * ld_out + c, acc);
+  }
+}
+
 // out[r] = a[ia[r]] - m[im[r]]
 template <int VEC>
 __global__ void __launch_bounds__(256) gather_diff_kernel(const float* __restrict__ a, int64_t ld_a,
@@ -222,6 +248,23 @@ int rr_gather_sum_f32(const float* src, int64_t n_src, int64_t ld_src, const int
     gather_sum_kernel<4><<<rr_grid_for(n_out * HV, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out);
   } else {
     gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out);
+  }
+  return rr_launch_status();
+}
+
+int rr_gather_sum_csr_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* offsets, const int32_t* idx,
+                          int64_t n_out, int H, float* out, int64_t ld_out, rr_stream_t stream) {
+  RR_CHECK_ARG(src && offsets && out && n_src >= 0 && n_out >= 0 && H >= 1 && ld_src >= H && ld_out >= H);
+  if (n_out == 0) return RR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(out);
+  if (vec) {
+    const int HV = H / 4;
+    gather_sum_csr_kernel<4><<<rr_grid_for(n_out * HV, 256), 256, 0, s>>>(src, ld_src, offsets, idx, n_out, HV, out,
+                                                                          ld_out);
+  } else {
+    gather_sum_csr_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, offsets, idx, n_out, H, out,
+                                                                         ld_out);
   }
   return rr_launch_status();
 }

@@ -105,6 +105,25 @@ def gather_sum(src: torch.Tensor, idx: torch.Tensor, H: int, out: torch.Tensor =
     return out
 
 
+def gather_sum_csr(src: torch.Tensor, offsets: torch.Tensor, idx: torch.Tensor, n_out: int, H: int) -> torch.Tensor:
+    """out[r] = sum of src[idx[j]] for j in [offsets[r], offsets[r+1]) — adjoint of a gather through a generic index."""
+    out = _new(src, n_out, H)
+    check(lib().rr_gather_sum_csr_f32(ptr(src), src.shape[0], _ld(src), ptr(offsets), ptr(idx), n_out, H, ptr(out),
+                                      _ld(out), stream()), "rr_gather_sum_csr_f32")
+    return out
+
+
+def _transpose_index(flat_idx: torch.Tensor, n_src: int):
+    """CSR transpose of a flat destination->source index, built on the device without any host sync:
+    (offsets [n_src+1] int32, dest [nnz] int32) with the destinations of every source row in increasing order."""
+    flat = flat_idx.reshape(-1).to(torch.int64)
+    order = torch.argsort(flat, stable=True)
+    counts = torch.bincount(flat, minlength=n_src)[:n_src]
+    offsets = torch.zeros(n_src + 1, dtype=torch.int32, device=flat.device)
+    offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return offsets, order.to(torch.int32)
+
+
 def gather_diff(a, ia, m, im, H: int, out=None):
     """out[r] = a[ia[r]] - m[im[r]] (models/mpn.py:91-92)."""
     n_out = ia.shape[0]
@@ -401,10 +420,12 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
             d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
                            dz_out=d_inp, dz_accumulate=not first)    # d_inp (+)= dZ on the way through
         else:
-            buf = torch.empty_like(d_msg) if (dz is None or dz is d_inp) else dz
-            dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
+            # H % 4 != 0: separate ReLU-backward pass.  dz is read by the weight-gradient stream, so every
+            # iteration gets a fresh buffer and d_inp accumulates in a buffer that stream never reads
+            # before the final W_i launch (which is ordered after all main-stream writes).
             if first:
-                d_inp = dz
+                d_inp = torch.zeros_like(d_msg)
+            dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=torch.empty_like(d_msg), acc=d_inp)
             wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it],
                   x1_sub_idx=g.b2revb, accumulate=(it != depth - 2), side=True)
             d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
@@ -563,10 +584,9 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
                 d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
                              dz_out=d_inp, dz_accumulate=not first)
             else:
-                buf = torch.empty_like(d_msg) if (dz is None or dz is d_inp) else dz
-                dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=buf, acc=d_inp)
-                if first:
-                    d_inp = dz
+                if first:                                            # see mpn_backward: fresh dz per iteration
+                    d_inp = torch.zeros_like(d_msg)
+                dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=torch.empty_like(d_msg), acc=d_inp)
                 wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2), side=True)
                 d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
             d_msg = gather_sum(d_a, g.a2a_t, H)                     # fresh buffer (side-stream readers)
@@ -634,7 +654,7 @@ class GatherSumFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, source, index):
-        src = _rowmajor(source, "source")
+        src = _rowmajor(source.detach(), "source")
         idx = index.to(torch.int32).contiguous()
         ctx.save_for_backward(idx)
         ctx.n_src = src.shape[0]
@@ -644,19 +664,46 @@ class GatherSumFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         idx, = ctx.saved_tensors
         go = _rowmajor(grad_out, "grad")
-        H = go.shape[1]
-        # transposed table built on the fly (generic index: use a sort); rows referenced many times are fine
-        flat = idx.reshape(-1).to(torch.int64)
-        order = torch.argsort(flat, stable=True)
-        rows = (order // idx.shape[1]).to(torch.int32)
-        counts = torch.bincount(flat, minlength=ctx.n_src)
-        kmax = int(counts.max().item()) if counts.numel() else 1
-        kmax = max(kmax, 1)
-        starts = torch.cumsum(counts, 0) - counts
-        tab = torch.full((ctx.n_src, kmax), -1, dtype=torch.int32, device=go.device)
-        pos = torch.arange(flat.numel(), device=go.device) - starts[flat[order]]
-        tab[flat[order], pos] = rows
-        return gather_sum(go, tab, H), None
+        K = idx.shape[1] if idx.dim() == 2 else 1
+        # d source[s] = sum over the (r, k) with index[r, k] == s of grad[r]: CSR transpose built on the device
+        offsets, dest = _transpose_index(idx, ctx.n_src)
+        rows = dest if K == 1 else torch.div(dest, K, rounding_mode="floor").to(torch.int32)
+        return gather_sum_csr(go, offsets, rows, ctx.n_src, go.shape[1]), None
+
+
+class IndexSelectNDFn(torch.autograd.Function):
+    """index_select_ND itself (utils.py:176-193): source[index] -> [n, K, H], differentiable in `source`
+    (autograd's index_select backward is a scatter-add; here a fixed-order CSR segment sum)."""
+
+    @staticmethod
+    def forward(ctx, source, index):
+        src = _rowmajor(source.detach(), "source")
+        n, K = index.shape
+        flat = index.reshape(-1, 1).to(torch.int32).contiguous()
+        ctx.save_for_backward(flat)
+        ctx.n_src = src.shape[0]
+        return gather_sum(src, flat, src.shape[1]).view(n, K, src.shape[1])
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        flat, = ctx.saved_tensors
+        H = grad_out.shape[-1]
+        go = _rowmajor(grad_out.reshape(-1, H), "grad")
+        offsets, dest = _transpose_index(flat, ctx.n_src)
+        return gather_sum_csr(go, offsets, dest, ctx.n_src, H), None
+
+
+class SegmentMeanFn(torch.autograd.Function):
+    """Per-molecule mean readout of atom hiddens (models/mpn.py:110-124), differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, g, H):
+        ctx.g, ctx.H = g, H
+        return segment_mean_fwd(_rowmajor(x.detach(), "atom hiddens"), g, H, None, 0, 0.0, 0)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return segment_mean_bwd(_rowmajor(dout, "grad"), ctx.g, ctx.H, 0, 0.0, 0), None, None
 
 
 class ReactionModelFn(torch.autograd.Function):
@@ -712,6 +759,9 @@ class ReactionModelFn(torch.autograd.Function):
     def backward(ctx, dout):
         st = ctx.st
         enc, dif, ffn = ctx.mods
+        if ctx.saved is None:
+            raise RuntimeError("ReactionModelFn: backward ran twice; the saved activations are released after the first "
+                               "backward (retain_graph=True is not supported by the explicit backward)")
         r_saved, p_saved, d_saved, f_saved, r_h, p_h = ctx.saved
         H, p, seed = st["H"], st["p"], st["seed"]
         rg, pg = st["r"], st["p_graph"]

@@ -52,7 +52,7 @@ class MPN(nn.Module):
         if self.return_atom_hiddens:
             return h
         # molecule readout (reference :110-124) — only the unused query encoder takes this path
-        return Fn.segment_mean_fwd(h.detach(), g, self.hidden_size, None, 0, 0.0, 0)
+        return Fn.SegmentMeanFn.apply(h, g, self.hidden_size)
 
 
 class MPNDiff(nn.Module):

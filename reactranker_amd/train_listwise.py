@@ -57,8 +57,11 @@ def train(model: torch.nn.Module, scheduler, train_batches: Union[Sequence, Call
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
     model = model.cuda(gpu)
-    if hasattr(model, "dropout_seed"):
-        model.dropout_seed = seed
+    # dropout streams: every forward draws a fresh stream seed from torch's generator (mpn._fresh_seed), which the
+    # manual_seed above makes reproducible - like the reference, whose nn.Dropout advances that generator per call.
+    # model.dropout_seed (a test knob that pins ONE stream for every step) must stay unset here.
+    if getattr(model, "dropout_seed", None) is not None:
+        model.dropout_seed = None
     score_old = [0.0, 0.0, 0.0] if save_metric == "all" else 0.0
     history = []
     say = logger.info if logger is not None else (lambda *_: None)

@@ -8,16 +8,12 @@ from . import functions as Fn
 
 
 def index_select_ND(source: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
-    """source[index] for a 2-D index -> [n, K, H] (reference utils.py:176-193).
+    """source[index] for a 2-D index -> [n, K, H] (reference utils.py:176-193), differentiable in `source`.
 
     Kept for API parity; the model itself never materialises this tensor — it calls
     functions.gather_sum, which fuses the following .sum(dim=1).
     """
-    n, K = index.shape
-    H = source.shape[1]
-    flat = index.reshape(-1, 1).to(torch.int32).contiguous()
-    out = Fn.gather_sum(Fn._rowmajor(source.detach(), "source"), flat, H)
-    return out.view(n, K, H)
+    return Fn.IndexSelectNDFn.apply(source, index)
 
 
 def index_select_sum(source: torch.Tensor, index: torch.Tensor) -> torch.Tensor:

@@ -132,9 +132,12 @@ def test_model_against_reference_vectors(path):
         nd.append(O.ndcg(rel[o], 10))
         off += cnt
     err = float(np.max(np.abs(sc1 - ref1)))
-    if min_gap > 2 * err:                                # ordering is only meaningful above the achieved error (H3)
-        assert np.array_equal(np.asarray(order, np.int32), d["order"])
-        assert np.allclose(nd, d["ndcg10"], rtol=0, atol=1e-12)
+    # ordering is only meaningful above the achieved error (hazard H3): every golden case has adjacent score gaps far
+    # above it, which is asserted (not assumed) so the ordering / NDCG@10 check below always runs
+    print(f"[ordering] {os.path.basename(path)}: min adjacent score gap {min_gap:.3e}, max |score err| {err:.3e}")
+    assert min_gap > 2 * err, f"golden case with a score gap {min_gap:.3e} below twice the achieved error {err:.3e}"
+    assert np.array_equal(np.asarray(order, np.int32), d["order"])
+    assert np.allclose(nd, d["ndcg10"], rtol=0, atol=1e-12)
 
 
 def _masks_for(model, seed, rg, pg, M, F, p):
