@@ -183,6 +183,13 @@ int rr_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out
 int rr_relu_bwd_f32(const float* dy, const float* y, float scale, float* dz, float* acc,
                     int64_t n, rr_stream_t stream);
 
+/* out = sum_{k<n_adds} adds[k] + dy * (y > 0) * scale.  `adds` is a HOST array of n_adds (<= 8) device pointers.
+ * The gradient of a residual read by several layers: `input` of models/mpn.py:80 enters every message-passing
+ * iteration (:94), so d input = sum_it dZ_it + relu'(input) * d message_0 - formed in one pass over memory from
+ * the per-iteration dZ buffers the input-gradient GEMMs write (rr_linear_args.dz_out). */
+int rr_relu_bwd_sum_f32(const float* dy, const float* y, float scale, const float* const* adds, int n_adds,
+                        float* out, int64_t n, rr_stream_t stream);
+
 /* out = alpha * a + beta * b   (b may be NULL).  diff = p_h - r_h (models/base_model.py:168). */
 int rr_axpby_f32(float alpha, const float* a, float beta, const float* b, float* out,
                  int64_t n, rr_stream_t stream);

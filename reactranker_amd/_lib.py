@@ -72,6 +72,7 @@ _SIGS = {
     "rr_dropout_keep_host": (i32, [u64, u64, f32]),
     "rr_dropout_f32": (i32, [c_f32p, i64, f32, u64, c_f32p, c_stream]),
     "rr_relu_bwd_f32": (i32, [c_f32p, c_f32p, f32, c_f32p, c_f32p, i64, c_stream]),
+    "rr_relu_bwd_sum_f32": (i32, [c_f32p, c_f32p, f32, C.POINTER(C.c_void_p), i32, c_f32p, i64, c_stream]),
     "rr_axpby_f32": (i32, [f32, c_f32p, f32, c_f32p, c_f32p, i64, c_stream]),
     "rr_head_fwd_f32": (i32, [c_f32p, i64, i32, i32, c_f32p, c_stream]),
     "rr_head_bwd_f32": (i32, [c_f32p, c_f32p, i64, i32, i32, c_f32p, c_stream]),

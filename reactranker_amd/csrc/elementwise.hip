@@ -30,6 +30,47 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__
   }
 }
 
+// out = sum_k adds[k] + (y > 0 ? dy * scale : 0): the gradient of a residual that several layers read
+// (d_inp = sum over the message-passing iterations of dZ_it, plus the ReLU-backward of the first layer) in
+// ONE pass over memory instead of a read-modify-write per iteration.
+constexpr int RR_MAX_ADDS = 8;
+struct AddPtrs {
+  const float* p[RR_MAX_ADDS];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) relu_bwd_sum_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           float scale, const AddPtrs adds, float* __restrict__ out,
+                                                           int64_t n4, int64_t n, int vec) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (vec) {
+    for (int64_t i = t0; i < n4; i += stride) {
+      const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+      const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+      f32x4 s = f32x4(0.f);
+      for (int k = 0; k < adds.n; ++k) s = s + reinterpret_cast<const f32x4*>(adds.p[k])[i];   // fixed order
+      f32x4 r;
+      r.x = v.x > 0.f ? g.x * scale : 0.f;
+      r.y = v.y > 0.f ? g.y * scale : 0.f;
+      r.z = v.z > 0.f ? g.z * scale : 0.f;
+      r.w = v.w > 0.f ? g.w * scale : 0.f;
+      reinterpret_cast<f32x4*>(out)[i] = s + r;
+    }
+    for (int64_t i = n4 * 4 + t0; i < n; i += stride) {
+      float s = 0.f;
+      for (int k = 0; k < adds.n; ++k) s += adds.p[k][i];
+      out[i] = s + (y[i] > 0.f ? dy[i] * scale : 0.f);
+    }
+  } else {
+    for (int64_t i = t0; i < n; i += stride) {
+      float s = 0.f;
+      for (int k = 0; k < adds.n; ++k) s += adds.p[k][i];
+      out[i] = s + (y[i] > 0.f ? dy[i] * scale : 0.f);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) relu_bwd_scalar_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               float scale, float* __restrict__ dz,
                                                               float* __restrict__ acc, int64_t n) {
@@ -173,6 +214,25 @@ int rr_relu_bwd_f32(const float* dy, const float* y, float scale, float* dz, flo
   } else {
     relu_bwd_scalar_kernel<<<rr_grid_for(n, 256), 256, 0, s>>>(dy, y, scale, dz, acc, n);
   }
+  return rr_launch_status();
+}
+
+int rr_relu_bwd_sum_f32(const float* dy, const float* y, float scale, const float* const* adds, int n_adds,
+                        float* out, int64_t n, rr_stream_t stream) {
+  RR_CHECK_ARG(dy && y && out && n >= 0 && n_adds >= 0 && n_adds <= RR_MAX_ADDS && (n_adds == 0 || adds));
+  if (n == 0) return RR_OK;
+  AddPtrs A;
+  A.n = n_adds;
+  bool vec = rr_aligned16(dy) && rr_aligned16(y) && rr_aligned16(out);
+  for (int k = 0; k < RR_MAX_ADDS; ++k) {
+    A.p[k] = k < n_adds ? adds[k] : nullptr;
+    if (k < n_adds) {
+      RR_CHECK_ARG(adds[k]);
+      vec = vec && rr_aligned16(adds[k]);
+    }
+  }
+  relu_bwd_sum_kernel<<<rr_grid_for(vec ? (n + 3) / 4 : n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      dy, y, scale, A, out, n / 4, n, vec ? 1 : 0);
   return rr_launch_status();
 }
 

@@ -46,6 +46,13 @@ struct LinearParams {
 __device__ __forceinline__ int swz(int row, int kq) { return kq ^ ((0 - (row >> 2)) & 3); }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Loads whose address is known to be GLOBAL memory.  A pointer that went through a select with a __device__
+// constant (the zero / ones chunks) is a generic pointer to hipcc, which then emits flat_load (counted on lgkmcnt
+// as well as vmcnt); these keep the weight-gradient loader on global_load (42 flat_load -> 0 in its ISA).
+typedef const __attribute__((address_space(1))) f32x4* rr_gptr4;
+typedef const __attribute__((address_space(1))) int32_t* rr_gptri;
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(rr_gptr4)(p); }
+__device__ __forceinline__ int32_t ldgi(const int32_t* p) { return *(rr_gptri)(p); }
 
 // LDS-DMA: 16 bytes per lane, global -> LDS at (wave-uniform byte address lds_dst) + lane * 16, no VGPR
 // destination.  Written as asm so that hipcc does not track it: its own bookkeeping treats an LDS-DMA in
@@ -859,8 +866,8 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
     for (int i = 0; i < S; ++i) {
       const int over = r0 + xrow[i] - (nrows - 1);      // > 0: past the end -> step back to the last row
       const int off = r0 - (over > 0 ? over : 0);
-      ia[i] = pi[i][off & gi[i]];                       // direct slots always read index 0 (>= 0, adds 0 rows)
-      if (HAS_SUB) is[i] = pj[i][off & gj[i]];
+      ia[i] = ldgi(pi[i] + (off & gi[i]));              // direct slots always read index 0 (>= 0, adds 0 rows)
+      if (HAS_SUB) is[i] = ldgi(pj[i] + (off & gj[i]));
     }
   };
   // rows_left < 16 only in the last tile of the M-chunk: those rows read the zero chunk.  No branches: every
@@ -869,18 +876,18 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       const bool zr = zrow[i] < rows_left;
-      zv[i] = ld4(zr ? pz[i] : zero);
-      if (HAS_MASK) zm[i] = ld4(zr ? pm[i] : zero);
+      zv[i] = ldg4(zr ? pz[i] : zero);
+      if (HAS_MASK) zm[i] = ldg4(zr ? pm[i] : zero);
       pz[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pz[i]) + zstep[i]);
       if (HAS_MASK) pm[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pm[i]) + mstep[i]);
       const bool xr = xrow[i] < rows_left;
       xrv[i] = xr;
       const float* p = px[i] + static_cast<uint64_t>(static_cast<uint32_t>(ia[i])) * static_cast<uint32_t>(a.ldx1);
-      xv[i] = ld4((xr && ia[i] >= 0) ? p : zero);
+      xv[i] = ldg4((xr && ia[i] >= 0) ? p : zero);
       px[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px[i]) + xstep[i]);
       if (HAS_SUB) {
         const float* q = ps[i] + static_cast<uint64_t>(static_cast<uint32_t>(is[i])) * static_cast<uint32_t>(a.ldx1_sub);
-        xs[i] = ld4((xr && is[i] >= 0) ? q : zero);
+        xs[i] = ldg4((xr && is[i] >= 0) ? q : zero);
         ps[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ps[i]) + sstep[i]);
       }
     }

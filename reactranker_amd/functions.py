@@ -280,6 +280,22 @@ def relu_bwd(dy, y, scale: float, dz=None, acc=None, want_dz=True):
     return dz
 
 
+MAX_ADDS = 8
+
+
+def relu_bwd_sum(dy, y, scale: float, adds):
+    """out = sum(adds) + dy * (y > 0) * scale in one pass (rr_relu_bwd_sum_f32); more than MAX_ADDS addends are
+    folded pairwise first."""
+    adds = list(adds)
+    while len(adds) > MAX_ADDS:
+        adds = [axpby(1.0, adds[0], 1.0, adds[1])] + adds[2:]
+    out = torch.empty_like(y)
+    arr = (C.c_void_p * max(1, len(adds)))(*[t.data_ptr() for t in adds])
+    check(lib().rr_relu_bwd_sum_f32(ptr(dy), ptr(y), float(scale), arr, len(adds), ptr(out), y.numel(), stream()),
+          "rr_relu_bwd_sum_f32")
+    return out
+
+
 def axpby(alpha: float, a, beta: float = 0.0, b=None, out=None):
     if out is None:
         out = torch.empty_like(a)
@@ -401,24 +417,33 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
     gWo, gbo = Wo.grads()
     gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
     # atom_hiddens = drop(relu([f_atoms | a_last] W_o^T + b_o))
-    wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
-    d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
+    fused = (H % 4 == 0)                                             # ReLU backward fused into the GEMM operand loads
+    # Fused form: the input-gradient GEMM applies the ReLU/dropout mask in its operand loader and writes the masked
+    # gradient dZ as a side output; the weight-gradient GEMM (other stream) then streams dZ as is - it reads no
+    # mask and applies none (one operand stream and 12 staging registers less: -14...-22 % on the bond-level launches).
+    if fused:
+        dz_o = torch.empty_like(dH)
+        d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks,
+                     dz_out=dz_o)
+        wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
+    else:
+        wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
+        d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
     # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)]
     d_msg = gather_sum(d_a, g.b2t, H)
     _pad_row_fix(d_msg, d_a, g, H)
     d_inp = None
-    fused = (H % 4 == 0)                                             # ReLU backward fused into the GEMM operand loads
-    dz = None
+    dzs = []                                                         # fused: one dZ buffer per iteration
     for it in reversed(range(depth - 1)):
         # msgs[it+1] = drop(relu(inp + m_in W_h^T + b_h)),  m_in = amsgs[it][b2a] - msgs[it][b2revb]
         first = d_inp is None
         if fused:
-            if first:
-                d_inp = torch.empty_like(d_msg)
-            wgrad(nB, H, d_msg, gWh, dbias=gbh, mask=msgs[it + 1], mask_scale=ks, x1=amsgs[it], k1=H, x1_idx=g.b2a,
-                  x1_sub=msgs[it], x1_sub_idx=g.b2revb, accumulate=(it != depth - 2), side=True)
+            dz = torch.empty_like(d_msg)                             # fresh: the weight-gradient stream reads it
             d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
-                           dz_out=d_inp, dz_accumulate=not first)    # d_inp (+)= dZ on the way through
+                           dz_out=dz)
+            wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
+                  accumulate=(it != depth - 2), side=True)
+            dzs.append(dz)
         else:
             # H % 4 != 0: separate ReLU-backward pass.  dz is read by the weight-gradient stream, so every
             # iteration gets a fresh buffer and d_inp accumulates in a buffer that stream never reads
@@ -432,8 +457,10 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
         d_a = gather_sum(d_min, g.a2b_rev_t, H)                     # sum over the atom's outgoing bonds
         d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H)          # fresh buffer: the side stream may still read the old one
         _pad_row_fix(d_msg, d_a, g, H)
-    # msgs[0] = relu(inp)
-    if d_inp is None:
+    # msgs[0] = relu(inp);  d inp = sum_it dZ_it + relu'(inp) * d msgs[0]   (inp is the residual of every iteration, :94)
+    if fused:
+        d_inp = relu_bwd_sum(d_msg, msgs[0], 1.0, dzs)
+    elif d_inp is None:
         d_inp = relu_bwd(d_msg, msgs[0], 1.0)
     else:
         relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
@@ -481,21 +508,21 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
     gWi, gbi = Wi.grads()
     gWo, gbo = Wo.grads()
     gWh, gbh = Wh.grads()
-    wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
-    d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
+    dz_o = torch.empty_like(dH)                                      # masked gradient as a side output (see mpn_backward)
+    d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks,
+                 dz_out=dz_o)
+    wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
     d_msg = gather_sum(d_a, g.b2t, H)
     _pad_row_fix(d_msg, d_a, g, H)
     d_inp_full = None
     wh_started = False
     for it in reversed(range(1, depth - 1)):                         # per-copy W_h layers
-        first = d_inp_full is None
-        if first:
-            d_inp_full = torch.empty_like(d_msg)
-        wgrad(nB, H, d_msg, gWh, dbias=gbh, mask=msgs[it + 1], mask_scale=ks, x1=amsgs[it], k1=H, x1_idx=g.b2a,
-              x1_sub=msgs[it], x1_sub_idx=g.b2revb, accumulate=wh_started, side=True)
+        dz = torch.empty_like(d_msg)
+        d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks, dz_out=dz)
+        wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
+              accumulate=wh_started, side=True)
         wh_started = True
-        d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
-                       dz_out=d_inp_full, dz_accumulate=not first)
+        d_inp_full = dz if d_inp_full is None else axpby(1.0, d_inp_full, 1.0, dz)   # fresh buffer (side-stream readers)
         d_a = gather_sum(d_min, g.a2b_rev_t, H)
         d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H)
         _pad_row_fix(d_msg, d_a, g, H)
@@ -564,25 +591,31 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
     d_hid = segment_mean_bwd(dvecs, g, H, F, out_drop_p, out_seed)                        # [nA,H]
     d_x = None
     if depth > 0:
-        wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx,
-              x2=a_last, k2=H, side=True)
-        # dX over both column segments of W_o: [d_x | d_a]
-        d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
+        fused = (H % 4 == 0)
+        # dX over both column segments of W_o: [d_x | d_a]; the first of the two GEMMs also writes the masked
+        # gradient dZ for the weight-gradient stream (see mpn_backward)
+        if fused:
+            dz_o = torch.empty_like(d_hid)
+            d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks, dz_out=dz_o)
+            wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx, x2=a_last, k2=H, side=True)
+        else:
+            wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx,
+                  x2=a_last, k2=H, side=True)
+            d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
         d_a = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
         d_msg = gather_sum(d_a, g.a2a_t, H)                        # neighbour relation is symmetric
         _pad_row_fix(d_msg, d_a, g, H)
-        d_inp, dz = None, None
-        fused = (H % 4 == 0)
+        d_inp = None
+        dzs = []
         fb = g.fb_sum() if depth > 1 else None
         for it in reversed(range(depth - 1)):
             first = d_inp is None
             if fused:
-                if first:
-                    d_inp = torch.empty_like(d_msg)
-                wgrad(nA, H, d_msg, gWh, dbias=gbh, mask=msgs[it + 1], mask_scale=ks, x1=amsgs[it], k1=H, x2=fb,
-                      k2=FBOND, accumulate=(it != depth - 2), side=True)
+                dz = torch.empty_like(d_msg)
                 d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
-                             dz_out=d_inp, dz_accumulate=not first)
+                             dz_out=dz)
+                wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2), side=True)
+                dzs.append(dz)
             else:
                 if first:                                            # see mpn_backward: fresh dz per iteration
                     d_inp = torch.zeros_like(d_msg)
@@ -591,7 +624,9 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
                 d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
             d_msg = gather_sum(d_a, g.a2a_t, H)                     # fresh buffer (side-stream readers)
             _pad_row_fix(d_msg, d_a, g, H)
-        if d_inp is None:
+        if fused:
+            d_inp = relu_bwd_sum(d_msg, msgs[0], 1.0, dzs)
+        elif d_inp is None:
             d_inp = relu_bwd(d_msg, msgs[0], 1.0)
         else:
             relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
