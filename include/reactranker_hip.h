@@ -330,6 +330,16 @@ int rr_derive_tables(const int32_t* a2b, const int32_t* b2a, const int32_t* b2re
                      int32_t* a2a, int32_t* a2b_rev_t, int32_t* b2t, int32_t* a2a_t,
                      float* npad, int32_t* atom2mol);
 
+/* Bond-to-bond backward table (HOST pointers), derived from the tables above.  The adjoint of
+ *   message[b] = a_message[b2a[b]] - message[b2revb[b]],  a_message[a] = sum_k message[a2b[a,k]]   (models/mpn.py:89-92)
+ * is  d message[b] = sum of d m_in over the bonds leaving atom target(b), minus d m_in[rev(b)]; rev(b) is one of those
+ * bonds, so it is a plain gather-sum over  b2b_t[nB, Kb]  (the bonds leaving target(b) except rev(b); pads -1;
+ * Kb >= max(1, K-1); row 0 all -1) - one pass instead of gather-sum + gather-diff.  The padding row's adjoint is the
+ * weighted column sum  sum_b npad_b[b] * d m_in[b]  with  npad_b[b] = npad[b2a[b]]  (npad_b[0] = K - 1). */
+int rr_derive_bond_tables(const int32_t* a2b_rev_t, const int32_t* b2t, const int32_t* b2revb, const int32_t* b2a,
+                          const float* npad, int64_t nA, int64_t nB, int K, int Kb,
+                          int32_t* b2b_t, float* npad_b);
+
 #ifdef __cplusplus
 }
 #endif

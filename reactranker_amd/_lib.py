@@ -101,6 +101,8 @@ _SIGS = {
                              C.c_void_p, C.c_void_p, i32, C.c_void_p, i64, C.c_void_p, i64, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "rr_derive_bond_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, i32,
+                                    C.c_void_p, C.c_void_p]),
     "rr_derive_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, C.c_void_p, i64, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

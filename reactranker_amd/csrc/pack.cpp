@@ -79,6 +79,29 @@ int rr_derive_tables(const int32_t* a2b, const int32_t* b2a, const int32_t* b2re
   return RR_OK;
 }
 
+int rr_derive_bond_tables(const int32_t* a2b_rev_t, const int32_t* b2t, const int32_t* b2revb, const int32_t* b2a,
+                          const float* npad, int64_t nA, int64_t nB, int K, int Kb, int32_t* b2b_t, float* npad_b) {
+  RR_CHECK_ARG(a2b_rev_t && b2t && b2revb && b2a && npad && nA >= 1 && nB >= 1 && K >= 1 && Kb >= 1 && Kb >= K - 1);
+  RR_CHECK_ARG(b2b_t && npad_b);
+  // row 0 (padding bond): rebuilt by the weighted column sum, no gathered sources
+  for (int j = 0; j < Kb; ++j) b2b_t[j] = -1;
+  npad_b[0] = npad[0] - 1.0f;                           // d_amsg[0] = d_min[0] is read K times, minus d_min[rev(0) = 0]
+  for (int64_t b = 1; b < nB; ++b) {
+    const int32_t t = b2t[b], r = b2revb[b], src = b2a[b];
+    RR_CHECK_ARG(t >= 0 && t < nA && src >= 0 && src < nA);
+    int n = 0;
+    for (int k = 0; k < K; ++k) {
+      const int32_t o = a2b_rev_t[static_cast<int64_t>(t) * K + k];   // bonds leaving the atom b points to
+      if (o < 0 || o == r) continue;
+      if (n >= Kb) return RR_ERR_ARG;
+      b2b_t[b * Kb + n++] = o;
+    }
+    for (; n < Kb; ++n) b2b_t[b * Kb + n] = -1;
+    npad_b[b] = npad[src];
+  }
+  return RR_OK;
+}
+
 int rr_pack_graphs(const int32_t* mol_atoms, const int32_t* mol_bonds, int64_t M, const float* f_atoms_cat,
                    int atom_fdim, const float* f_bonds_cat, int bond_fdim, const int32_t* b2a_local,
                    const int32_t* b2revb_local, const int64_t* a2b_off, const int32_t* a2b_local, int K,

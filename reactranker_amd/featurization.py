@@ -125,14 +125,15 @@ class DeviceGraph:
     """A packed batch resident in HBM: features, index arrays and backward tables."""
 
     __slots__ = ("device", "nA", "nB", "K", "M", "f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope",
-                 "a2b_rev_t", "b2t", "a2a_t", "npad", "atom2mol", "_fb_sum", "bytes")
+                 "a2b_rev_t", "b2t", "a2a_t", "npad", "atom2mol", "b2b_t", "npad_b", "_fb_sum", "bytes")
 
     def __init__(self, host: dict, device):
         self.device = torch.device(device)
         self.nA, self.nB, self.K, self.M = host["nA"], host["nB"], host["K"], host["M"]
         self.bytes = 0
+        _bond_tables(host)
         for k in ("f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope", "a2b_rev_t", "b2t", "a2a_t", "npad",
-                  "atom2mol"):
+                  "atom2mol", "b2b_t", "npad_b"):
             t = torch.from_numpy(host[k]).to(self.device, non_blocking=False)
             setattr(self, k, t)
             self.bytes += t.numel() * t.element_size()
@@ -147,6 +148,20 @@ class DeviceGraph:
             buf = torch.zeros(self.nA, self.f_bonds.shape[1], dtype=torch.float32, device=self.device)  # ld 84
             self._fb_sum = Fn.gather_sum(self.f_bonds, self.a2b, w, out=buf)
         return self._fb_sum
+
+
+def _bond_tables(host: dict) -> None:
+    """Adds the bond-to-bond backward table b2b_t / npad_b (rr_derive_bond_tables) to a packed-batch dict."""
+    if "b2b_t" in host:
+        return
+    nA, nB, K = host["nA"], host["nB"], host["K"]
+    Kb = max(1, K - 1)
+    host["b2b_t"] = np.empty((nB, Kb), np.int32)
+    host["npad_b"] = np.empty(nB, np.float32)
+    _lib.check(_lib.lib().rr_derive_bond_tables(
+        _lib.np_ptr(host["a2b_rev_t"]), _lib.np_ptr(host["b2t"]), _lib.np_ptr(host["b2revb"]), _lib.np_ptr(host["b2a"]),
+        _lib.np_ptr(host["npad"]), nA, nB, K, Kb, _lib.np_ptr(host["b2b_t"]), _lib.np_ptr(host["npad_b"])),
+        "rr_derive_bond_tables")
 
 
 def _pack(arrs, K_override: int) -> dict:
@@ -184,6 +199,7 @@ def _pack(arrs, K_override: int) -> dict:
         _lib.np_ptr(out["a_scope"]), _lib.np_ptr(out["a2b_rev_t"]), _lib.np_ptr(out["b2t"]),
         _lib.np_ptr(out["a2a_t"]), _lib.np_ptr(out["npad"]), _lib.np_ptr(out["atom2mol"])), "rr_pack_graphs")
     out.update(nA=nA, nB=nB, K=K, M=M, atom_fdim=atom_fdim, bond_fdim=bond_fdim)
+    _bond_tables(out)
     return out
 
 

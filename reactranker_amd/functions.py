@@ -401,6 +401,16 @@ def mpn_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p
     return h, (msgs, amsgs, a_last, h)
 
 
+def bond_message_adjoint(d_min, g, H: int):
+    """Adjoint of  message = a_message[b2a] - message[b2revb],  a_message = sum_k message[a2b]  (models/mpn.py:89-92):
+    d message[b] = sum of d_min over the bonds leaving target(b) except rev(b) - ONE gather-sum over the packer's
+    bond-to-bond table (rr_derive_bond_tables) instead of gather-sum + gather-diff; the padding row's adjoint
+    (row 0 is read K - deg(a) times by atom a) is the weighted column sum over d_min."""
+    d_msg = gather_sum(d_min, g.b2b_t, H)
+    weighted_colsum(d_min, g.npad_b, H, d_msg[0], accumulate=True)
+    return d_msg
+
+
 def _pad_row_fix(d_src, d_out, g, H):
     """Row 0 of every gathered source is read npad[a] times by atom a (a2b is right-padded with
     bond/atom 0, features/featurization.py:286): add sum_a npad[a] * d_out[a] to d_src[0]."""
@@ -454,9 +464,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
             wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it],
                   x1_sub_idx=g.b2revb, accumulate=(it != depth - 2), side=True)
             d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
-        d_a = gather_sum(d_min, g.a2b_rev_t, H)                     # sum over the atom's outgoing bonds
-        d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H)          # fresh buffer: the side stream may still read the old one
-        _pad_row_fix(d_msg, d_a, g, H)
+        d_msg = bond_message_adjoint(d_min, g, H)                   # fresh buffer: the side stream may still read the old one
     # msgs[0] = relu(inp);  d inp = sum_it dZ_it + relu'(inp) * d msgs[0]   (inp is the residual of every iteration, :94)
     if fused:
         d_inp = relu_bwd_sum(d_msg, msgs[0], 1.0, dzs)
@@ -523,9 +531,7 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
               accumulate=wh_started, side=True)
         wh_started = True
         d_inp_full = dz if d_inp_full is None else axpby(1.0, d_inp_full, 1.0, dz)   # fresh buffer (side-stream readers)
-        d_a = gather_sum(d_min, g.a2b_rev_t, H)
-        d_msg = gather_diff(d_a, g.b2t, d_min, g.b2revb, H)
-        _pad_row_fix(d_msg, d_a, g, H)
+        d_msg = bond_message_adjoint(d_min, g, H)
     # ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
     dz1_full = relu_bwd(d_msg, msgs[1], ks)                           # (msgs[1] > 0) <=> kept and z1 > 0
     dz1_u = gather_sum(dz1_full, bmap_t, H)                           # sum over the copies
@@ -537,9 +543,7 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
     wgrad(nBu, H, dz1_u, gWh, dbias=gbh, x1=a0_u, k1=H, x1_idx=gu.b2a, x1_sub=msg0_u, x1_sub_idx=gu.b2revb,
           accumulate=wh_started, side=True)
     d_min_u = linear(nBu, H, Wh.pk_t(0, H), w_packed=True, a1=dz1_u, k1=H)
-    d_a_u = gather_sum(d_min_u, gu.a2b_rev_t, H)
-    d_msg0_u = gather_diff(d_a_u, gu.b2t, d_min_u, gu.b2revb, H)
-    _pad_row_fix(d_msg0_u, d_a_u, gu, H)
+    d_msg0_u = bond_message_adjoint(d_min_u, gu, H)
     relu_bwd(d_msg0_u, msg0_u, 1.0, acc=d_inp_u, want_dz=False)       # msg0 = relu(inp)
     wgrad(nBu, H, d_inp_u, gWi, dbias=gbi, x1=gu.f_bonds, k1=FBOND, side=True)
     return gWi, gbi, gWh, gbh, gWo, gbo

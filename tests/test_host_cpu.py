@@ -100,6 +100,30 @@ def test_backward_tables_are_the_transposes():
     assert a_msg.shape == (nA, 5)
 
 
+@pytest.mark.parametrize("K", [None, 6])
+def test_bond_to_bond_table_is_the_adjoint_of_the_bond_message(K):
+    """b2b_t / npad_b (rr_derive_bond_tables): d message = adjoint of
+    m_in[b] = (sum_k msg[a2b[b2a[b], k]]) - msg[b2revb[b]]  (models/mpn.py:89-92), pad row included."""
+    qb = synth.make_queries(11, 4, [3, 1, 4, 2], atoms_lo=4, atoms_hi=10)
+    b = featurization.BatchMolGraph(qb.p_specs, K=K)
+    h = b._host
+    nA, nB, Kk = h["nA"], h["nB"], h["K"]
+    assert h["b2b_t"].shape == (nB, max(1, Kk - 1)) and h["npad_b"].shape == (nB,)
+    rng = np.random.default_rng(1)
+    d_min = rng.standard_normal((nB, 7))
+    # brute-force adjoint by scattering through the forward's own index arrays
+    want = np.zeros((nB, 7))
+    d_amsg = np.zeros((nA, 7))
+    np.add.at(d_amsg, h["b2a"], d_min)                                  # a_msg[b2a[b]] term
+    np.add.at(want, h["a2b"].reshape(-1), np.repeat(d_amsg, Kk, axis=0))  # a_msg[a] = sum_k msg[a2b[a,k]]
+    np.add.at(want, h["b2revb"], -d_min)                                # - msg[b2revb[b]]
+    t = h["b2b_t"]
+    got = np.where(t[..., None] >= 0, d_min[np.maximum(t, 0)], 0.0).sum(1)
+    got[0] += (h["npad_b"][:, None] * d_min).sum(0)
+    assert np.allclose(got, want)
+    assert (t[0] == -1).all() and h["npad_b"][0] == Kk - 1
+
+
 def test_pack_rejects_too_small_k_and_handles_empty():
     qb = synth.make_queries(1, 1, [2])
     with pytest.raises(RuntimeError):
