@@ -64,6 +64,15 @@ int rr_gather_sum_csr_f32(const float* src, int64_t n_src, int64_t ld_src,
                           const int32_t* offsets, const int32_t* idx, int64_t n_out, int H,
                           float* out, int64_t ld_out, rr_stream_t stream);
 
+/* f_bonds[b, :] = [ f_atoms[b2a[b], 0:atom_fdim] | fbond[b, 0:bond_fdim] | zeros up to ld_out ]
+ * The reference stores a directed bond's feature row as its source atom's features followed by the bond's own
+ * (features/featurization.py:198-199), i.e. 61 of the 83 columns repeat f_atoms.  A packed step therefore ships only the
+ * bond columns (reactranker_amd/shards.py) and this kernel rebuilds the [n_bonds, ld_out] array in HBM.  b2a values must
+ * lie in [0, n_atoms). */
+int rr_build_fbonds_f32(const float* f_atoms, int64_t n_atoms, int64_t ld_fa, int atom_fdim, const int32_t* b2a,
+                        const float* fbond, int64_t ld_fbb, int bond_fdim, int64_t n_bonds,
+                        float* out, int64_t ld_out, rr_stream_t stream);
+
 /* out[r] = (ia[r] >= 0 ? a[ia[r]] : 0) - (im[r] >= 0 ? m[im[r]] : 0)
  * Replaces  message = a_message[b2a] - message[b2revb]  (models/mpn.py:91-92); with the
  * transposed tables (b2t, b2revb) it is that line's backward. */

@@ -130,6 +130,25 @@ __global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __rest
   }
 }
 
+// f_bonds[b] = [ f_atoms[b2a[b], 0:Fa] | fbond[b, 0:Fb] | 0 ... ]  (features/featurization.py:198-199: a directed bond's
+// feature row is its source atom's features followed by the bond's own) - rebuilt on the device so that only the
+// Fb bond columns travel over PCIe with a packed step (the atom half is 3x the bytes and already resident).
+__global__ void __launch_bounds__(256) build_fbonds_kernel(const float* __restrict__ f_atoms, int64_t ld_fa, int Fa,
+                                                           const int32_t* __restrict__ b2a,
+                                                           const float* __restrict__ fbond, int64_t ld_fbb, int Fb,
+                                                           int64_t nB, float* __restrict__ out, int64_t ld_out) {
+  const int64_t total = nB * ld_out;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t b = e / ld_out;
+    const int c = static_cast<int>(e - b * ld_out);
+    float v = 0.f;
+    if (c < Fa) v = f_atoms[static_cast<int64_t>(b2a[b]) * ld_fa + c];
+    else if (c < Fa + Fb) v = fbond[b * ld_fbb + (c - Fa)];
+    out[e] = v;
+  }
+}
+
 // stage 1 of the deterministic weighted column sum: block b sums its row chunk.  256 threads =
 // RL row-lanes x CG column groups of 4 floats (H = 300 -> 75 groups x 3 row-lanes), so every lane
 // issues 16-byte loads; the row-lanes are combined through LDS in a fixed order.
@@ -305,6 +324,17 @@ int rr_gather_dropout_f32(const float* src, int64_t n_src, int64_t ld_src, const
     gather_dropout_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, idx, n_out, H, H, thr, ks,
                                                                          drop_seed, out, ld_out);
   }
+  return rr_launch_status();
+}
+
+int rr_build_fbonds_f32(const float* f_atoms, int64_t n_atoms, int64_t ld_fa, int atom_fdim, const int32_t* b2a,
+                        const float* fbond, int64_t ld_fbb, int bond_fdim, int64_t n_bonds, float* out, int64_t ld_out,
+                        rr_stream_t stream) {
+  RR_CHECK_ARG(f_atoms && b2a && fbond && out && n_atoms >= 1 && n_bonds >= 0 && atom_fdim >= 1 && bond_fdim >= 0);
+  RR_CHECK_ARG(ld_fa >= atom_fdim && ld_fbb >= bond_fdim && ld_out >= atom_fdim + bond_fdim);
+  if (n_bonds == 0) return RR_OK;
+  build_fbonds_kernel<<<rr_grid_for(n_bonds * ld_out, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      f_atoms, ld_fa, atom_fdim, b2a, fbond, ld_fbb, bond_fdim, n_bonds, out, ld_out);
   return rr_launch_status();
 }
 

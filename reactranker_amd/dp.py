@@ -25,6 +25,9 @@ def shard_queries(n_queries: int, rank: int, world: int):
 class GradBucket:
     """Flat fp32 gradient bucket (3.16 MB at H=300: latency-bound, so exactly one collective)."""
 
+    profile = False          # bench.py: record a HIP-event pair around every collective (class-wide switch)
+    events: List = []        # [(start, end)] on the compute stream, filled while `profile` is on
+
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
@@ -51,7 +54,14 @@ class GradBucket:
         torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
         if local_weight != 1.0:
             self.flat.mul_(local_weight)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if GradBucket.profile and self.flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            e1.record()
+            GradBucket.events.append((e0, e1))
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         torch._foreach_copy_([p.grad for p in self.params], list(self._views))
 
 

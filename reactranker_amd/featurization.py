@@ -121,33 +121,103 @@ def _concat_ducks(graphs):
     return mol_atoms, mol_bonds, f_atoms_cat, f_bonds_cat, b2a_local, b2revb_local, a2b_off, a2b_local
 
 
-class DeviceGraph:
-    """A packed batch resident in HBM: features, index arrays and backward tables."""
+_GRAPH_KEYS = ("f_atoms", "a2b", "b2a", "b2revb", "a2a", "a_scope", "a2b_rev_t", "b2t", "a2a_t", "npad", "atom2mol",
+               "b2b_t", "npad_b")
 
-    __slots__ = ("device", "nA", "nB", "K", "M", "f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope",
-                 "a2b_rev_t", "b2t", "a2a_t", "npad", "atom2mol", "b2b_t", "npad_b", "_fb_sum", "bytes")
+
+class DeviceGraph:
+    """A packed batch resident in HBM: features, index arrays and backward tables.
+
+    `f_bonds` ([nB, 84]: source-atom features ++ bond features, featurization.py:198-199) is either uploaded as is
+    (host batches) or rebuilt on the device from `f_atoms[b2a]` and the bond-only columns `fbond`
+    (rr_build_fbonds_f32; batches streamed from a shard file carry only the 22 bond columns)."""
+
+    __slots__ = ("device", "nA", "nB", "K", "M", "f_atoms", "_f_bonds", "fbond", "a2b", "b2a", "b2revb", "a2a", "a_scope",
+                 "a2b_rev_t", "b2t", "a2a_t", "npad", "atom2mol", "b2b_t", "npad_b", "_fb_sum", "bytes", "atom_fdim",
+                 "bond_fdim")
 
     def __init__(self, host: dict, device):
         self.device = torch.device(device)
         self.nA, self.nB, self.K, self.M = host["nA"], host["nB"], host["K"], host["M"]
+        self.atom_fdim = int(host.get("atom_fdim", ATOM_FDIM))
+        self.bond_fdim = int(host.get("bond_fdim", ATOM_FDIM + BOND_FDIM)) - self.atom_fdim
         self.bytes = 0
         _bond_tables(host)
-        for k in ("f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope", "a2b_rev_t", "b2t", "a2a_t", "npad",
-                  "atom2mol", "b2b_t", "npad_b"):
+        for k in _GRAPH_KEYS + ("f_bonds",):
             t = torch.from_numpy(host[k]).to(self.device, non_blocking=False)
-            setattr(self, k, t)
+            setattr(self, "_f_bonds" if k == "f_bonds" else k, t)
             self.bytes += t.numel() * t.element_size()
+        self.fbond = None
         self._fb_sum = None
+
+    @classmethod
+    def from_device(cls, tensors: dict, nA: int, nB: int, K: int, M: int, device, atom_fdim: int = ATOM_FDIM,
+                    bond_fdim: int = BOND_FDIM) -> "DeviceGraph":
+        """Wrap tensors that already live in HBM (views into a prefetched step buffer).  `tensors` holds the index
+        tables, `f_atoms` and either `f_bonds` or the bond-only columns `fbond` [nB, >= bond_fdim]."""
+        g = cls.__new__(cls)
+        g.device = torch.device(device)
+        g.nA, g.nB, g.K, g.M = int(nA), int(nB), int(K), int(M)
+        g.atom_fdim, g.bond_fdim = int(atom_fdim), int(bond_fdim)
+        g.bytes = 0
+        for k in _GRAPH_KEYS:
+            t = tensors[k]
+            if not t.is_cuda:
+                raise RuntimeError(f"DeviceGraph.from_device: `{k}` must already be on the GPU")
+            setattr(g, k, t)
+            g.bytes += t.numel() * t.element_size()
+        g._f_bonds = tensors.get("f_bonds")
+        g.fbond = tensors.get("fbond")
+        if g._f_bonds is None and g.fbond is None:
+            raise RuntimeError("DeviceGraph.from_device needs `f_bonds` or the bond-only columns `fbond`")
+        g._fb_sum = None
+        return g
+
+    @property
+    def f_bonds(self):
+        if self._f_bonds is None:
+            ld = (self.atom_fdim + self.bond_fdim + 3) // 4 * 4
+            out = torch.empty(self.nB, ld, dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().rr_build_fbonds_f32(
+                _lib.ptr(self.f_atoms), self.nA, self.f_atoms.stride(0), self.atom_fdim, _lib.ptr(self.b2a),
+                _lib.ptr(self.fbond), self.fbond.stride(0), self.bond_fdim, self.nB, _lib.ptr(out), ld,
+                _lib.stream()), "rr_build_fbonds_f32")
+            self._f_bonds = out
+        return self._f_bonds
 
     def fb_sum(self):
         """sum_k f_bonds[a2b[a,k]]  ([nA, 84]) — the bond-feature half of MPNDiff's neighbour sum
         (reference models/mpn.py:202-209).  Input-only, so it is computed once per batch and cached."""
         if self._fb_sum is None:
             from . import functions as Fn
-            w = BOND_FDIM + ATOM_FDIM
-            buf = torch.zeros(self.nA, self.f_bonds.shape[1], dtype=torch.float32, device=self.device)  # ld 84
-            self._fb_sum = Fn.gather_sum(self.f_bonds, self.a2b, w, out=buf)
+            fb = self.f_bonds
+            w = self.atom_fdim + self.bond_fdim
+            buf = torch.zeros(self.nA, fb.shape[1], dtype=torch.float32, device=self.device)  # ld 84
+            self._fb_sum = Fn.gather_sum(fb, self.a2b, w, out=buf)
         return self._fb_sum
+
+
+class DeviceBatch:
+    """A packed batch that exists in HBM only (what reactranker_amd.shards.StepPrefetcher yields): the model takes it
+    wherever it takes a BatchMolGraph.  Carries the de-duplication maps of BatchMolGraph.unique() as device tensors."""
+
+    def __init__(self, graph: DeviceGraph, unique: "DeviceBatch" = None, amap=None, amap_t=None, bmap=None, bmap_t=None):
+        self.graph = graph
+        self.n_mols, self.n_atoms, self.n_bonds, self.max_num_bonds = graph.M, graph.nA, graph.nB, graph.K
+        self._ub = unique
+        if unique is not None:
+            key = str(graph.device)
+            self._rr_dedup_dev = (key, amap, amap_t)             # the caches base_model.ReactionModel.forward reads
+            self._rr_prefix_dev = (key, bmap, bmap_t)
+
+    def device_graph(self, gpu=None) -> DeviceGraph:
+        return self.graph
+
+    def unique(self):
+        return (self if self._ub is None else self._ub), None, None
+
+    def unique_bonds(self):
+        return None, None
 
 
 def _bond_tables(host: dict) -> None:
@@ -215,12 +285,20 @@ class BatchMolGraph:
         self.atom_fdim = get_atom_fdim()
         self.bond_fdim = get_bond_fdim() + self.atom_fdim
         specs = [g.spec if isinstance(g, MolGraph) else g for g in graphs]
-        self._specs = specs                      # kept for unique(): repeated molecule objects are de-duplicated by identity
         if all(isinstance(s, MolSpec) for s in specs):
             arrs = _concat_specs(specs)
         else:
             arrs = _concat_ducks(specs)
-        self._host = _pack(arrs, 0 if K is None else int(K))
+        self._init_from_arrays(arrs, 0 if K is None else int(K), self.smiles_batch, specs)
+
+    def _init_from_arrays(self, arrs, K: int, smiles, specs):
+        self.smiles_batch = list(smiles)
+        self.n_mols = len(self.smiles_batch)
+        self.atom_fdim = get_atom_fdim()
+        self.bond_fdim = get_bond_fdim() + self.atom_fdim
+        self._specs = specs                      # kept for unique(): repeated molecule objects are de-duplicated by identity
+        self._mol_ids = None if specs is not None else np.arange(self.n_mols, dtype=np.int32)
+        self._host = _pack(arrs, int(K))
         h = self._host
         self.n_atoms, self.n_bonds = h["nA"], h["nB"]
         self.max_num_bonds = h["K"]
@@ -274,16 +352,12 @@ class BatchMolGraph:
         built as different objects are not merged."""
         if getattr(self, "_unique", None) is not None:
             return self._unique
-        first, uidx = {}, []
-        for s in self._specs:
-            k = id(s)
-            if k not in first:
-                first[k] = len(first)
-            uidx.append(first[k])
-        useq = [None] * len(first)
-        for s, u in zip(self._specs, uidx):
-            useq[u] = s
-        ub = BatchMolGraph(useq, K=self.max_num_bonds) if len(useq) else BatchMolGraph([], K=None)
+        uidx = self.molecule_ids()
+        n_u = int(uidx.max()) + 1 if len(uidx) else 0
+        firsts = np.full(n_u, -1, np.int64)
+        for m in range(len(uidx) - 1, -1, -1):
+            firsts[uidx[m]] = m                                # first occurrence of every distinct molecule
+        ub = self.subset(firsts)
         if ub.max_num_bonds != self.max_num_bonds:
             raise RuntimeError("unique(): pad width mismatch")
         h, hu = self._host, ub._host
@@ -318,6 +392,53 @@ class BatchMolGraph:
         self._unique = (ub, amap, amap_t)
         return self._unique
 
+    def molecule_ids(self) -> np.ndarray:
+        """[n_mols] int32: id of the distinct molecule each batch entry repeats (ids in order of first occurrence).
+        Identity-based when the batch was built from molecule objects; stored with packed batches (save_packed)."""
+        ids = getattr(self, "_mol_ids", None)
+        if ids is None:
+            first, out = {}, []
+            for s in self._specs:
+                k = id(s)
+                if k not in first:
+                    first[k] = len(first)
+                out.append(first[k])
+            ids = np.asarray(out, np.int32)
+            self._mol_ids = ids
+        return ids
+
+    def subset(self, mol_ids) -> "BatchMolGraph":
+        """A new batch holding the molecules `mol_ids` (in that order), rebuilt from this batch's packed arrays with
+        the same pad width - e.g. the distinct reactants of unique(), or a rank's block of whole queries."""
+        mol_ids = np.asarray(mol_ids, np.int64).reshape(-1)
+        h = self._host
+        K = h["K"]
+        afd, bfd = h["atom_fdim"], h["bond_fdim"]
+        a_sc = h["a_scope"].astype(np.int64)
+        b_sc = np.asarray(self.b_scope, np.int64).reshape(-1, 2)
+        mol_atoms = a_sc[mol_ids, 1].astype(np.int32) if len(mol_ids) else np.zeros(0, np.int32)
+        mol_bonds = b_sc[mol_ids, 1].astype(np.int32) if len(mol_ids) else np.zeros(0, np.int32)
+
+        def rows(scope_start, sizes):
+            rep = np.repeat(np.arange(len(sizes)), sizes)
+            within = np.arange(int(sizes.sum())) - np.repeat(np.cumsum(sizes) - sizes, sizes)
+            return scope_start[rep] + within, rep
+        arow, amol = rows(a_sc[mol_ids, 0], mol_atoms.astype(np.int64)) if len(mol_ids) else (np.zeros(0, np.int64),) * 2
+        brow, bmol = rows(b_sc[mol_ids, 0], mol_bonds.astype(np.int64)) if len(mol_ids) else (np.zeros(0, np.int64),) * 2
+        f_atoms_cat = np.ascontiguousarray(h["f_atoms"][arow, :afd])
+        f_bonds_cat = np.ascontiguousarray(h["f_bonds"][brow, :bfd])
+        b2a_local = (h["b2a"][brow] - a_sc[mol_ids, 0][bmol]).astype(np.int32)
+        b2revb_local = (h["b2revb"][brow] - b_sc[mol_ids, 0][bmol]).astype(np.int32)
+        deg = (K - h["npad"][arow]).astype(np.int64)
+        a2b_off = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        a2b_rows = h["a2b"][arow]                                            # [n, K], real entries first
+        keep = np.arange(K)[None, :] < deg[:, None]
+        a2b_local = (a2b_rows - b_sc[mol_ids, 0][amol][:, None])[keep].astype(np.int32)
+        sub = BatchMolGraph.__new__(BatchMolGraph)
+        sub._init_from_arrays((mol_atoms, mol_bonds, f_atoms_cat, f_bonds_cat, b2a_local, b2revb_local, a2b_off, a2b_local),
+                              K, [self.smiles_batch[i] for i in mol_ids], None)
+        return sub
+
     def get_a2a(self):
         return self.a2a
 
@@ -339,7 +460,7 @@ def device_graph_of(batch, gpu) -> DeviceGraph:
     get_components()/get_a2a() contract (e.g. the reference's own BatchMolGraph)."""
     if isinstance(batch, DeviceGraph):
         return batch
-    if isinstance(batch, BatchMolGraph):
+    if isinstance(batch, (BatchMolGraph, DeviceBatch)):
         return batch.device_graph(gpu)
     cache = getattr(batch, "_rr_device_graphs", None)
     if cache is None:
@@ -389,25 +510,29 @@ _PACK_KEYS = ("f_atoms", "f_bonds", "a2b", "b2a", "b2revb", "a2a", "a_scope", "a
 
 
 def save_packed(batch: BatchMolGraph, path: str) -> None:
-    """Write a packed batch (features, index arrays, backward tables) so a dataset is packed once, not per epoch
-    (the reference re-runs BatchMolGraph's Python list packing for every batch of every epoch)."""
+    """Write a packed batch (features, index arrays, backward tables, molecule identities) so a dataset is packed
+    once, not per epoch (the reference re-runs BatchMolGraph's Python list packing for every batch of every epoch).
+    For whole training steps streamed from disk see reactranker_amd.shards."""
     h = batch._host
     np.savez(path, **{k: h[k] for k in _PACK_KEYS},
              meta=np.asarray([h["nA"], h["nB"], h["K"], h["M"], h["atom_fdim"], h["bond_fdim"]], np.int64),
-             b_scope=np.asarray(batch.b_scope, np.int64).reshape(-1, 2))
+             b_scope=np.asarray(batch.b_scope, np.int64).reshape(-1, 2), mol_ids=batch.molecule_ids())
 
 
 def load_packed(path: str) -> BatchMolGraph:
-    """Inverse of save_packed: a BatchMolGraph backed by the stored arrays (no re-packing)."""
+    """Inverse of save_packed: a BatchMolGraph backed by the stored arrays (no re-packing).  The stored molecule
+    identities let unique() / unique_bonds() (reactant de-duplication) work exactly as on the original batch."""
     d = np.load(path if path.endswith(".npz") else path + ".npz")
     b = BatchMolGraph.__new__(BatchMolGraph)
     nA, nB, K, M, afd, bfd = (int(v) for v in d["meta"])
     b._host = {k: np.ascontiguousarray(d[k]) for k in _PACK_KEYS}
     b._host.update(nA=nA, nB=nB, K=K, M=M, atom_fdim=afd, bond_fdim=bfd)
+    _bond_tables(b._host)
     b.smiles_batch, b.n_mols = [""] * M, M
     b.atom_fdim, b.bond_fdim = get_atom_fdim(), get_bond_fdim() + get_atom_fdim()
     b.n_atoms, b.n_bonds, b.max_num_bonds = nA, nB, K
     b.a_scope = [tuple(int(v) for v in r) for r in b._host["a_scope"]]
     b.b_scope = [tuple(int(v) for v in r) for r in d["b_scope"]]
     b.b2b, b._dev, b._specs = None, {}, None
+    b._mol_ids = np.asarray(d["mol_ids"], np.int32) if "mol_ids" in d.files else np.arange(M, dtype=np.int32)
     return b

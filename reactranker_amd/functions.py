@@ -758,7 +758,7 @@ class ReactionModelFn(torch.autograd.Function):
         ffn = [LinW(params[i], params[i + 1]) for i in range(12, len(params), 2)]
         H, p, seed = st["H"], st["p"], st["seed"]
         rg, pg = st["r"], st["p_graph"]
-        dev = rg.f_bonds.device
+        dev = rg.device
         main = torch.cuda.current_stream(dev)
         px = st.get("prefix")                                        # (distinct reactant graph, bmap, bmap_t) or None
 
