@@ -37,6 +37,8 @@ def _loss(kind, out, scope, targets):
         return O.listnet_loss(out, scope, targets), None
     if kind == "mse":
         return O.mse_loss(out, targets), None
+    if kind == "evidential_ranking":                             # loss.py:554: sum over queries / number of queries
+        return O.evidential_ranking_loss(out, scope, targets).sum(), None
     ls, pairs = O.ranknet_sum_session(out, scope, targets, 1.0)
     return ls, pairs
 
@@ -51,7 +53,8 @@ def _grads(kind, w, qb, lo, hi, K):
         g = O.graph_tensors(O.pack_batch(specs, K=K))
         g["f_atoms"], g["f_bonds"] = g["f_atoms"].double(), g["f_bonds"].double()
         return g
-    out = O.reaction_forward(P, CFG, g64(qb.r_specs[m0:m1]), g64(qb.p_specs[m0:m1]),
+    cfg = dict(CFG, task_type="evidential_ranking") if kind == "evidential_ranking" else CFG
+    out = O.reaction_forward(P, cfg, g64(qb.r_specs[m0:m1]), g64(qb.p_specs[m0:m1]),
                              torch.tensor(qb.add_features[m0:m1]).double())
     loss, pairs = _loss(kind, out, qb.scope[lo:hi], torch.tensor(qb.targets[m0:m1]).double())
     if kind == "ranknet":
@@ -66,7 +69,7 @@ def _worker(rank, world, port, kind, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
-        shapes = O.model_shapes(H, 2, 2, 2, 1, 1, True)
+        shapes = O.model_shapes(H, 2, 2, 2, 2 if kind == "evidential_ranking" else 1, 1, True)
         w = synth.seeded_weights(shapes, 3)
         qb = synth.make_queries(99, len(SCOPE), SCOPE, atoms_lo=4, atoms_hi=8)
         K = 4                                                    # global pad width on every rank (hazard H1)
@@ -86,7 +89,7 @@ def _worker(rank, world, port, kind, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["mle", "listnet", "mse", "ranknet"])
+@pytest.mark.parametrize("kind", ["mle", "listnet", "mse", "ranknet", "evidential_ranking"])
 def test_weighted_allreduce_equals_single_process_gradient(kind):
     world = 2
     mgr = mp.Manager()
