@@ -538,8 +538,8 @@ def main():
             try:
                 log(f"preset {name}: building 2 steps")
                 del_R = Runner(name, pc, args, rank, world, local, device, 2)
-                for i in range(3):
-                    del_R.train_step(del_R.pool[i % 2])
+                for i in range(6):                        # un-synchronised, like the timed loop: lets the caching
+                    del_R.train_step(del_R.pool[i % 2])   # allocator reach its steady state (no hipMalloc while timing)
                 secs, per, lastp = del_R.timed(lambda i: del_R.pool[i % 2], args.preset_steps)
                 tp = torch.tensor([secs], dtype=torch.float64, device=device)
                 if world > 1:
@@ -567,7 +567,6 @@ def main():
                     final_loss=round(float(lastp.detach().sum().cpu()), 6))
                 log(f"preset {name}: {presets[name]['ms_per_step']} ms/step")
                 del del_R
-                torch.cuda.empty_cache()
             except Exception as e:                        # noqa: BLE001
                 presets[name] = dict(error=f"{type(e).__name__}: {e}")
                 log(f"preset {name} failed: {presets[name]['error']}")

@@ -1,8 +1,10 @@
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes as
 MI355X_MICROARCH.md prescribes).  gfx950 correction: FETCH_SIZE reports 1/2 of a wide coalesced stream's
 bytes -> doubled; WRITE_SIZE is exact.  Units in the CSV are KiB.  Writes profiles/<tag>_traffic.json."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # noqa: E402  (bench.py trusts the file only while the kernel sources still hash to this)
 
 
 def load(d, counter):
@@ -27,5 +29,5 @@ for k in sorted(set(fe) | set(wr)):
     res[k] = dict(fetch_kib_raw=round(f, 1), write_kib=round(w, 1), launches=int(cf.get(k, cw.get(k, 0))),
                   hbm_bytes_per_launch=int((2.0 * f + w) * 1024))
 json.dump(dict(note="avg per launch over the bench's kernel mix; FETCH_SIZE doubled (gfx950 half-count of wide reads)",
-               kernels=res), open(out, "w"), indent=1)
+               csrc_hash=csrc_hash(), kernels=res), open(out, "w"), indent=1)
 print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in list(res.items())[:8]}))
