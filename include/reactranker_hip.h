@@ -56,6 +56,14 @@ int rr_gather_sum_f32(const float* src, int64_t n_src, int64_t ld_src,
                       const int32_t* idx, int64_t n_out, int K, int H,
                       float* out, int64_t ld_out, rr_stream_t stream);
 
+/* rr_gather_sum_f32 whose output row 0 is instead the fixed-order sum of `n_partial` partial rows
+ * (row0_partial[i, 0:H], i ascending): the padding row's adjoint delivered by rr_linear_args.colsum_partial.
+ * The one wavefront that owns row 0 does the sum while the others gather - no extra pass, no extra launch. */
+int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src,
+                             const int32_t* idx, int64_t n_out, int K, int H,
+                             const float* row0_partial, int64_t n_partial, int64_t ld_partial,
+                             float* out, int64_t ld_out, rr_stream_t stream);
+
 /* out[r, 0:H] = sum_{j in [offsets[r], offsets[r+1])} src[idx[j], 0:H]   (CSR form, offsets has n_out+1 entries)
  * The adjoint of index_select_ND (utils.py:176-193) for a GENERIC index tensor: autograd's index_select
  * backward is a scatter-add; here the sources of every destination row are listed (sorted by destination, stable)
@@ -129,7 +137,7 @@ typedef struct rr_linear_args {
   float* dz_out;         int64_t ld_dz;     int dz_accumulate;  /* with a_mask: also materialise the masked operand,
                                                        dz_out[m,k] (+)= A[m,k] — e.g. d_input += dZ of every
                                                        message-passing step (the residual `input +` of mpn.py:95).
-                                                       Needs k1 % 4 == 0, 16-byte aligned rows, N <= 304. */
+                                                       Needs k1 % 4 == 0 and 16-byte aligned rows. */
   const float* w;        int64_t ldw;               /* [N, k1+k2] row-major (nn.Linear.weight), or */
   int w_packed;                                     /* 1: the zero-padded layout of rr_pack_weight_f32 */
   const float* bias;                                /* [N] or NULL */
@@ -142,9 +150,19 @@ typedef struct rr_linear_args {
   float* c_pre;          int64_t ld_pre;            /* optional second output: the pre-activation value
                                                        (input = W_i(f_bonds) next to message = relu(input),
                                                        models/mpn.py:80-81) */
+  const float* colsum_w;                            /* optional third output (fast path only): per-row weights w[M] ... */
+  float* colsum_partial; int64_t ld_partial;        /* ... and partial[rr_linear_colsum_rows(M), ld_partial >= N]:
+                                                       partial[i, n] = sum over the 64 rows of row block i of w[m]*C[m,n].
+                                                       The padding row's adjoint (a2b is right-padded with bond 0,
+                                                       features/featurization.py:286, so row 0 of a gathered source
+                                                       receives sum_a npad[a] * d_out[a]) falls out of the GEMM that
+                                                       produces d_out instead of a separate pass over it; the partial
+                                                       rows are summed, in order, by rr_gather_sum_padrow_f32. */
 } rr_linear_args;
 
 int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream);
+/* Row blocks (= partial rows written through colsum_partial) of an M-row call. */
+int64_t rr_linear_colsum_rows(int64_t M);
 
 /* Packed weight layout for the straight-line fast path of rr_linear_f32:
  *   dst[r, 0:k1] = L[r, 0:k1];  dst[r, r16(k1) : r16(k1)+k2] = L[r, k1:k1+k2];  zeros elsewhere;

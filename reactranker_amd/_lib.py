@@ -36,6 +36,7 @@ class LinearArgs(C.Structure):
         ("act", i32), ("drop_p", f32), ("drop_seed", u64),
         ("c", c_f32p), ("ldc", i64),
         ("c_pre", c_f32p), ("ld_pre", i64),
+        ("colsum_w", c_f32p), ("colsum_partial", c_f32p), ("ld_partial", i64),
     ]
 
 
@@ -66,6 +67,8 @@ _SIGS = {
     "rr_colsum_workspace_bytes": (C.c_size_t, [i64, i32]),
     "rr_weighted_colsum_f32": (i32, [c_f32p, i64, i64, c_f32p, i32, c_f32p, i32, C.c_void_p, C.c_size_t, c_stream]),
     "rr_linear_f32": (i32, [C.POINTER(LinearArgs), c_stream]),
+    "rr_linear_colsum_rows": (i64, [i64]),
+    "rr_gather_sum_padrow_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, c_f32p, i64, c_stream]),
     "rr_packed_weight_ld": (i64, [i32, i32]),
     "rr_pack_weight_f32": (i32, [c_f32p, i64, i32, i32, i32, i32, i32, c_f32p, c_stream]),
     "rr_linear_wgrad_workspace_bytes": (C.c_size_t, [i64, i32, i32]),
@@ -109,7 +112,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 

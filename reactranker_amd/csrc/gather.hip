@@ -28,13 +28,44 @@ __device__ __attribute__((aligned(16))) const float gather_zero[4] = {0.f, 0.f, 
 template <int VEC>
 __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict__ src, int64_t ld_src,
                                                          const int32_t* __restrict__ idx, int64_t n_out, int K,
-                                                         int HV, float* __restrict__ out, int64_t ld_out) {
+                                                         int HV, float* __restrict__ out, int64_t ld_out,
+                                                         const float* __restrict__ row0_partial, int64_t n_partial,
+                                                         int64_t ld_partial) {
   using V = typename Vec<VEC>::T;
   const int64_t total = n_out * HV;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  // With a padding-row reduction the LAST HV blocks of the grid do that instead of gathering: block j sums column
+  // group j of all partial rows (256 threads stride over the rows, then a fixed-order LDS + shuffle tree) and writes
+  // out[0, group j] - the reduction runs next to the gather instead of as a straggler thread or an extra launch.
+  const int gblocks = row0_partial ? static_cast<int>(gridDim.x) - HV : static_cast<int>(gridDim.x);
+  if (row0_partial != nullptr && static_cast<int>(blockIdx.x) >= gblocks) {
+    __shared__ float red[256 * VEC];
+    const int c = (static_cast<int>(blockIdx.x) - gblocks) * VEC;
+    V a0 = V(0.f), a1 = V(0.f);
+    int64_t i = threadIdx.x;
+    for (; i + 256 < n_partial; i += 512) {
+      a0 = a0 + ld<VEC>(row0_partial + i * ld_partial + c);
+      a1 = a1 + ld<VEC>(row0_partial + (i + 256) * ld_partial + c);
+    }
+    if (i < n_partial) a0 = a0 + ld<VEC>(row0_partial + i * ld_partial + c);
+    st<VEC>(&red[threadIdx.x * VEC], a0 + a1);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      V v = (ld<VEC>(&red[threadIdx.x * VEC]) + ld<VEC>(&red[(threadIdx.x + 64) * VEC])) +
+            (ld<VEC>(&red[(threadIdx.x + 128) * VEC]) + ld<VEC>(&red[(threadIdx.x + 192) * VEC]));
+      if constexpr (VEC == 4) {
+        v.x = rr_wave_sum(v.x); v.y = rr_wave_sum(v.y); v.z = rr_wave_sum(v.z); v.w = rr_wave_sum(v.w);
+      } else {
+        v = rr_wave_sum(v);
+      }
+      if (threadIdx.x == 0) st<VEC>(out + c, v);
+    }
+    return;
+  }
+  const int64_t stride = static_cast<int64_t>(gblocks) * blockDim.x;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * VEC;
+    if (r == 0 && row0_partial != nullptr) continue;          // written by the reduction blocks
     const int32_t* ir = idx + r * K;
     V acc = V(0.0f);
     int k = 0;
@@ -264,9 +295,30 @@ int rr_gather_sum_f32(const float* src, int64_t n_src, int64_t ld_src, const int
   const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(out);
   if (vec) {
     const int HV = H / 4;
-    gather_sum_kernel<4><<<rr_grid_for(n_out * HV, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out);
+    gather_sum_kernel<4><<<rr_grid_for(n_out * HV, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out,
+                                                                      nullptr, 0, 0);
   } else {
-    gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out);
+    gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out,
+                                                                     nullptr, 0, 0);
+  }
+  return rr_launch_status();
+}
+
+int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
+                             int H, const float* row0_partial, int64_t n_partial, int64_t ld_partial, float* out,
+                             int64_t ld_out, rr_stream_t stream) {
+  RR_CHECK_ARG(src && idx && out && n_src >= 0 && n_out >= 1 && K >= 1 && H >= 1 && ld_src >= H && ld_out >= H);
+  RR_CHECK_ARG(row0_partial && n_partial >= 0 && ld_partial >= H);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && (ld_partial % 4 == 0) && rr_aligned16(src) &&
+                   rr_aligned16(out) && rr_aligned16(row0_partial);
+  if (vec) {
+    const int HV = H / 4;
+    gather_sum_kernel<4><<<rr_grid_for(n_out * HV, 256) + HV, 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out,
+                                                                           row0_partial, n_partial, ld_partial);
+  } else {
+    gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256) + H, 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out,
+                                                                         row0_partial, n_partial, ld_partial);
   }
   return rr_launch_status();
 }

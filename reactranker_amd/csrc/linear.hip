@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
   }
   const bool has_bias = a.bias != nullptr;
   const bool relu = a.act == RR_ACT_RELU;
-  auto finish = [&](f32x4 v, int n) {                  // activation + dropout + store of one chunk
+  auto finish = [&](f32x4 v, int n) -> f32x4 {         // activation + dropout + store of one chunk; returns what was stored
     if (relu) {
       v.x = fmaxf(v.x, 0.f);
       v.y = fmaxf(v.y, 0.f);
@@ -510,8 +510,16 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
       for (int e = 0; e < 4; ++e) v[e] = rr_hash_lane(w, e) >= P.drop_thr ? v[e] * P.keep_scale : 0.f;
     }
     if (row_ok && n < a.N) *reinterpret_cast<f32x4*>(crow + n) = v;
+    return v;
   };
   float* prow = a.c_pre ? a.c_pre + mc * a.ld_pre : nullptr;   // pre-activation side output (W_i layers)
+  // Optional third output: partial[blockIdx.x, n] = sum over this workgroup's 64 rows of w[m] * C[m, n] (the padding
+  // row's adjoint, see rr_linear_args.colsum_partial).  A lane holds 4 columns of ONE row per tile, the 16 rows of a
+  // wave sit in the 16 lanes of a DPP row: four row_shr adds leave the 16-row sum in lane 15 of every row, which
+  // parks it in the (now idle) k-loop LDS; after the tile loop 76 threads add the four waves' slices in wave order.
+  const bool cs_on = a.colsum_partial != nullptr;
+  const float wrow = (cs_on && row_ok) ? a.colsum_w[mc] : 0.f;
+  float* const cs_lds = &lds[0][0];                    // [4 waves][BN]
   {
     const bool res_ok = rrow != nullptr;
     const float* rbase = res_ok ? rrow : dummy;
@@ -537,7 +545,29 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
       for (int e = 0; e < 4; ++e) v[e] = res_ok ? vr[e] : v[e];
       if (tc + D < NT) ring[(tc + D) % (D + 1)] = ldres(tc + D);
       if (prow != nullptr && row_ok && n < a.N) *reinterpret_cast<f32x4*>(prow + n) = v;
-      finish(v, n);
+      const f32x4 stored = finish(v, n);
+      if (cs_on) {
+        f32x4 t = stored * wrow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = t[e];
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));   // row_shr:1
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));   // row_shr:2
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));   // row_shr:4
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));   // row_shr:8
+          t[e] = x;
+        }
+        if (fr == 15) *reinterpret_cast<f32x4*>(cs_lds + wave * BN + tc * 16 + nq) = t;
+      }
+    }
+  }
+  if (cs_on) {
+    __syncthreads();
+    if (tid < BN / 4) {
+      const int n = n0 + tid * 4;
+      const f32x4 s01 = ld4(cs_lds + tid * 4) + ld4(cs_lds + BN + tid * 4);
+      const f32x4 s23 = ld4(cs_lds + 2 * BN + tid * 4) + ld4(cs_lds + 3 * BN + tid * 4);
+      if (n < a.N) *reinterpret_cast<f32x4*>(a.colsum_partial + static_cast<int64_t>(blockIdx.x) * a.ld_partial + n) = s01 + s23;
     }
   }
 #ifdef RR_TRACE
@@ -1149,6 +1179,10 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   if (a.dz_out) {                                     // side output only exists on the straight-line path
     if (!fast || a.k1 % 4 != 0 || !vec_ok(a.dz_out, a.ld_dz)) return RR_ERR_ALIGN;
   }
+  if (a.colsum_partial) {                             // likewise the weighted column-sum side output
+    RR_CHECK_ARG(a.colsum_w && a.ld_partial >= a.N);
+    if (!fast || !vec_ok(a.colsum_partial, a.ld_partial)) return RR_ERR_ALIGN;
+  }
   if (a.N <= 64) return launch_linear<4>(P, s, fast);
   if (a.N <= 160) return launch_linear<10>(P, s, fast);
   return launch_linear<19>(P, s, fast);
@@ -1164,6 +1198,8 @@ int rr_pack_weight_f32(const float* src, int64_t ld_src, int transpose, int rows
 }
 
 int64_t rr_packed_weight_ld(int k1, int k2) { return r16(k1) + r16(k2); }
+
+int64_t rr_linear_colsum_rows(int64_t M) { return M <= 0 ? 0 : (M + BM - 1) / BM; }
 
 size_t rr_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
   if (M < 0 || N < 1 || K < 1) return 0;

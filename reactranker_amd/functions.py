@@ -93,15 +93,22 @@ def _new(like: torch.Tensor, *shape) -> torch.Tensor:
 
 
 # =========================================================================== layer 1
-def gather_sum(src: torch.Tensor, idx: torch.Tensor, H: int, out: torch.Tensor = None) -> torch.Tensor:
-    """out[r] = sum_k src[idx[r,k]] — index_select_ND + sum(dim=1) (utils.py:176-193; models/mpn.py:89-90)."""
+def gather_sum(src: torch.Tensor, idx: torch.Tensor, H: int, out: torch.Tensor = None, row0_partial=None) -> torch.Tensor:
+    """out[r] = sum_k src[idx[r,k]] — index_select_ND + sum(dim=1) (utils.py:176-193; models/mpn.py:89-90).
+    row0_partial [n, >=H]: output row 0 (the padding row) is the fixed-order sum of these rows instead — the
+    weighted column sums a dX GEMM wrote next to its output (linear(..., colsum_w=...))."""
     n_out, K = (idx.shape[0], idx.shape[1]) if idx.dim() == 2 else (idx.shape[0], 1)
     if out is None:
         out = _new(src, n_out, H)
     # algorithmic bytes: every source row once, every output row once, the index table once
     with _Timed("gather_sum_kernel", 0, 4 * (src.shape[0] * H + n_out * H + n_out * K)):
-        check(lib().rr_gather_sum_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), n_out, K, H, ptr(out), _ld(out),
-                                      stream()), "rr_gather_sum_f32")
+        if row0_partial is None:
+            check(lib().rr_gather_sum_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), n_out, K, H, ptr(out), _ld(out),
+                                          stream()), "rr_gather_sum_f32")
+        else:
+            check(lib().rr_gather_sum_padrow_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), n_out, K, H,
+                                                 ptr(row0_partial), row0_partial.shape[0], _ld(row0_partial), ptr(out),
+                                                 _ld(out), stream()), "rr_gather_sum_padrow_f32")
     return out
 
 
@@ -155,11 +162,15 @@ def weighted_colsum(x, w, H: int, out, accumulate: bool):
 
 def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub_idx=None, a2=None, k2=0, a_mask=None,
            mask_scale=1.0, ldw=None, w_packed=False, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0,
-           out=None, c_pre=None, dz_out=None, dz_accumulate=False, residual_idx=None):
-    """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h)."""
+           out=None, c_pre=None, dz_out=None, dz_accumulate=False, residual_idx=None, colsum_w=None):
+    """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h).
+    colsum_w [M]: also returns the per-row-block partial sums of colsum_w[m] * out[m, :]  ->  (out, partial)."""
     ref = a1 if a1 is not None else a2
     if out is None:
         out = _new(ref, M, N)
+    partial = None
+    if colsum_w is not None:
+        partial = _new(ref, int(lib().rr_linear_colsum_rows(M)), (N + 3) // 4 * 4)
     A = LinearArgs()
     A.M, A.N = M, N
     A.a1, A.lda1, A.k1, A.a1_idx = ptr(a1), _ld(a1), k1, ptr(a1_idx)
@@ -173,6 +184,7 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.act, A.drop_p, A.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
     A.c, A.ldc = ptr(out), _ld(out)
     A.c_pre, A.ld_pre = ptr(c_pre), _ld(c_pre)
+    A.colsum_w, A.colsum_partial, A.ld_partial = ptr(colsum_w), ptr(partial), _ld(partial)
     nt = 4 if N <= 64 else (10 if N <= 160 else 19)
     mode = 2 if a_mask is not None else (1 if a1_sub is not None else 0)
     kk = k1 + k2
@@ -183,7 +195,7 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     kern = "linear_fast_kernel" if w_packed else "linear_kernel"
     with _Timed(f"{kern}<{nt},{mode}>", 2 * M * N * kk, nbytes):
         check(lib().rr_linear_f32(C.byref(A), stream()), "rr_linear_f32")
-    return out
+    return out if colsum_w is None else (out, partial)
 
 
 class SideStream:
@@ -401,11 +413,13 @@ def mpn_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p
     return h, (msgs, amsgs, a_last, h)
 
 
-def bond_message_adjoint(d_min, g, H: int):
+def bond_message_adjoint(d_min, g, H: int, partial=None):
     """Adjoint of  message = a_message[b2a] - message[b2revb],  a_message = sum_k message[a2b]  (models/mpn.py:89-92):
     d message[b] = sum of d_min over the bonds leaving target(b) except rev(b) - ONE gather-sum over the packer's
     bond-to-bond table (rr_derive_bond_tables) instead of gather-sum + gather-diff; the padding row's adjoint
     (row 0 is read K - deg(a) times by atom a) is the weighted column sum over d_min."""
+    if partial is not None:                              # the GEMM that produced d_min already summed npad_b[b] * d_min[b]
+        return gather_sum(d_min, g.b2b_t, H, row0_partial=partial)
     d_msg = gather_sum(d_min, g.b2b_t, H)
     weighted_colsum(d_min, g.npad_b, H, d_msg[0], accumulate=True)
     return d_msg
@@ -433,15 +447,17 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
     # mask and applies none (one operand stream and 12 staging registers less: -14...-22 % on the bond-level launches).
     if fused:
         dz_o = torch.empty_like(dH)
-        d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks,
-                     dz_out=dz_o)
+        # ... and the padding row's adjoint sum_a npad[a] * d_a[a] as per-row-block partial sums (colsum_w)
+        d_a, part = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h,
+                           mask_scale=sign * ks, dz_out=dz_o, colsum_w=g.npad)
         wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
+        # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)]
+        d_msg = gather_sum(d_a, g.b2t, H, row0_partial=part)
     else:
         wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
         d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
-    # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)]
-    d_msg = gather_sum(d_a, g.b2t, H)
-    _pad_row_fix(d_msg, d_a, g, H)
+        d_msg = gather_sum(d_a, g.b2t, H)
+        _pad_row_fix(d_msg, d_a, g, H)
     d_inp = None
     dzs = []                                                         # fused: one dZ buffer per iteration
     for it in reversed(range(depth - 1)):
@@ -449,11 +465,13 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
         first = d_inp is None
         if fused:
             dz = torch.empty_like(d_msg)                             # fresh: the weight-gradient stream reads it
-            d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
-                           dz_out=dz)
+            d_min, part = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
+                                 dz_out=dz, colsum_w=g.npad_b)
             wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
                   accumulate=(it != depth - 2), side=True)
             dzs.append(dz)
+            d_msg = bond_message_adjoint(d_min, g, H, part)          # fresh buffer: the side stream may still read the old one
+            continue
         else:
             # H % 4 != 0: separate ReLU-backward pass.  dz is read by the weight-gradient stream, so every
             # iteration gets a fresh buffer and d_inp accumulates in a buffer that stream never reads
@@ -464,7 +482,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
             wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it],
                   x1_sub_idx=g.b2revb, accumulate=(it != depth - 2), side=True)
             d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
-        d_msg = bond_message_adjoint(d_min, g, H)                   # fresh buffer: the side stream may still read the old one
+        d_msg = bond_message_adjoint(d_min, g, H)
     # msgs[0] = relu(inp);  d inp = sum_it dZ_it + relu'(inp) * d msgs[0]   (inp is the residual of every iteration, :94)
     if fused:
         d_inp = relu_bwd_sum(d_msg, msgs[0], 1.0, dzs)
@@ -517,21 +535,21 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
     gWo, gbo = Wo.grads()
     gWh, gbh = Wh.grads()
     dz_o = torch.empty_like(dH)                                      # masked gradient as a side output (see mpn_backward)
-    d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks,
-                 dz_out=dz_o)
+    d_a, part = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks,
+                       dz_out=dz_o, colsum_w=g.npad)
     wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
-    d_msg = gather_sum(d_a, g.b2t, H)
-    _pad_row_fix(d_msg, d_a, g, H)
+    d_msg = gather_sum(d_a, g.b2t, H, row0_partial=part)
     d_inp_full = None
     wh_started = False
     for it in reversed(range(1, depth - 1)):                         # per-copy W_h layers
         dz = torch.empty_like(d_msg)
-        d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks, dz_out=dz)
+        d_min, part = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
+                             dz_out=dz, colsum_w=g.npad_b)
         wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
               accumulate=wh_started, side=True)
         wh_started = True
         d_inp_full = dz if d_inp_full is None else axpby(1.0, d_inp_full, 1.0, dz)   # fresh buffer (side-stream readers)
-        d_msg = bond_message_adjoint(d_min, g, H)
+        d_msg = bond_message_adjoint(d_min, g, H, part)
     # ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
     dz1_full = relu_bwd(d_msg, msgs[1], ks)                           # (msgs[1] > 0) <=> kept and z1 > 0
     dz1_u = gather_sum(dz1_full, bmap_t, H)                           # sum over the copies
@@ -542,8 +560,8 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
         d_inp_u = dz1_u.clone()
     wgrad(nBu, H, dz1_u, gWh, dbias=gbh, x1=a0_u, k1=H, x1_idx=gu.b2a, x1_sub=msg0_u, x1_sub_idx=gu.b2revb,
           accumulate=wh_started, side=True)
-    d_min_u = linear(nBu, H, Wh.pk_t(0, H), w_packed=True, a1=dz1_u, k1=H)
-    d_msg0_u = bond_message_adjoint(d_min_u, gu, H)
+    d_min_u, part_u = linear(nBu, H, Wh.pk_t(0, H), w_packed=True, a1=dz1_u, k1=H, colsum_w=gu.npad_b)
+    d_msg0_u = bond_message_adjoint(d_min_u, gu, H, part_u)
     relu_bwd(d_msg0_u, msg0_u, 1.0, acc=d_inp_u, want_dz=False)       # msg0 = relu(inp)
     wgrad(nBu, H, d_inp_u, gWi, dbias=gbi, x1=gu.f_bonds, k1=FBOND, side=True)
     return gWi, gbi, gWh, gbh, gWo, gbo
@@ -606,9 +624,14 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
             wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx,
                   x2=a_last, k2=H, side=True)
             d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
-        d_a = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
-        d_msg = gather_sum(d_a, g.a2a_t, H)                        # neighbour relation is symmetric
-        _pad_row_fix(d_msg, d_a, g, H)
+        if fused:
+            d_a, part = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks,
+                               colsum_w=g.npad)
+            d_msg = gather_sum(d_a, g.a2a_t, H, row0_partial=part)  # neighbour relation is symmetric
+        else:
+            d_a = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
+            d_msg = gather_sum(d_a, g.a2a_t, H)
+            _pad_row_fix(d_msg, d_a, g, H)
         d_inp = None
         dzs = []
         fb = g.fb_sum() if depth > 1 else None
@@ -616,10 +639,12 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
             first = d_inp is None
             if fused:
                 dz = torch.empty_like(d_msg)
-                d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
-                             dz_out=dz)
+                d_a, part = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
+                                   dz_out=dz, colsum_w=g.npad)
                 wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2), side=True)
                 dzs.append(dz)
+                d_msg = gather_sum(d_a, g.a2a_t, H, row0_partial=part)   # fresh buffer (side-stream readers)
+                continue
             else:
                 if first:                                            # see mpn_backward: fresh dz per iteration
                     d_inp = torch.zeros_like(d_msg)

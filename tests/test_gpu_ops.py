@@ -275,3 +275,40 @@ def test_relu_bwd_axpby_head_segment():
         go = torch.randn(50, N)
         ref.backward(go)
         close(Fn.head_bwd(go.cuda(), raw.cuda(), head), r.grad, what=f"head bwd {head}")
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 300, 300), (63, 300, 300), (64, 32, 32), (4099, 300, 300), (1000, 600, 300),
+                                   (70001, 300, 300)])
+def test_linear_weighted_colsum_side_output_and_padrow_gather(M, N, K):
+    """rr_linear_args.colsum_partial: per-row-block partial sums of w[m] * C[m, :] next to the GEMM output, consumed by
+    rr_gather_sum_padrow_f32 as output row 0 (the padding row's adjoint, features/featurization.py:286)."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    y = torch.relu(torch.randn(M, K, generator=g))                 # ReLU mask source (MODE 2, the backward's usual caller)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    rw = torch.randint(0, 5, (M,), generator=g).float()            # npad-like weights
+    W = Fn.LinW(w.cuda(), None)
+    dz = torch.empty(M, K).cuda()
+    out, part = Fn.linear(M, N, W.pk(K), w_packed=True, a1=a.cuda(), k1=K, a_mask=y.cuda(), mask_scale=1.25, dz_out=dz,
+                          colsum_w=rw.cuda())
+    az = (a * (y > 0) * 1.25).double()
+    ref = az @ w.double().t()
+    close(out, ref.float(), tol=2e-5, what="C")
+    assert part.shape[0] == (M + 63) // 64 == int(_lib.lib().rr_linear_colsum_rows(M))
+    want = (rw.double()[:, None] * ref).sum(0)
+    got = part[:, :N].double().sum(0).cpu()
+    scale = float((rw.double()[:, None] * ref.abs()).sum(0).max()) + 1e-30      # size of the summed terms
+    assert float((got - want).abs().max()) <= 2e-6 * scale
+    # plain kernels (no mask) write it too; and the gather's row 0 = ordered sum of the partial rows
+    out2, part2 = Fn.linear(M, N, W.pk(K), w_packed=True, a1=dz, k1=K, colsum_w=rw.cuda())
+    assert torch.equal(out2, out) and torch.equal(part2, part)
+    n_out, Kt = 77, 3
+    idx = torch.randint(-1, M, (n_out, Kt), generator=g).to(torch.int32)
+    idx[0] = -1
+    gs = Fn.gather_sum(out, idx.cuda(), N, row0_partial=part)
+    plain = Fn.gather_sum(out, idx.cuda(), N)
+    assert torch.equal(gs[1:], plain[1:]) and float(plain[0].abs().max()) == 0.0
+    s = torch.zeros(N, dtype=torch.float32).cuda()
+    ref0 = part[:, :N].double().sum(0)
+    assert float((gs[0].double() - ref0).abs().max()) <= 2e-6 * scale
+    assert torch.equal(Fn.gather_sum(out, idx.cuda(), N, row0_partial=part)[0], gs[0])     # fixed order: bit-stable
