@@ -1070,12 +1070,11 @@ int64_t wgrad_want_chunks(int64_t M, int N, int kext) {
   const int tiles = ((N + WBN - 1) / WBN) * ((kext + WBN - 1) / WBN);
   // One round of workgroups (2 fit per CU: a 513th would wait a whole round).  Chunk c runs on XCD c % 8
   // (XCD-aware mapping), so the chunk count is a multiple of 8: otherwise some XCDs get one more chunk than their
-  // 64 slots hold.  384 rather than 512: the weight gradients run on a side stream next to the dX chain, and a
-  // workgroup of this kernel holds ~half a SIMD's registers - with 2 per CU everywhere a main-stream kernel cannot
-  // become resident until the whole wgrad launch has drained; leaving every other CU with one free slot lets
-  // the critical path keep moving (step -2 % against 512, although this kernel alone is 29 % slower with 384).
+  // 64 slots hold.  Round 1 ran 384 here (the masked / subtracting loader held ~250 VGPRs and starved the dX chain on
+  // the main stream); with the mask applied by the dX GEMM (dZ side output) the kernels are leaner and the full
+  // 512 wins: step -1.1 % (same-box A/B: 448 -0.6 %, 320 +2.4 %), this kernel alone -20...-29 %.
 #ifndef RR_WGRAD_WGS
-#define RR_WGRAD_WGS 384
+#define RR_WGRAD_WGS 512
 #endif
   int64_t want = RR_WGRAD_WGS / tiles;
   if (want >= 8) want -= want % 8;
