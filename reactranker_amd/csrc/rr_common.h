@@ -1,6 +1,11 @@
 // Shared host/device helpers for the gfx950 kernels behind include/reactranker_hip.h.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else            // host-only translation unit (the AddressSanitizer build of pack.cpp: `make asan`, plain g++)
+#define __host__
+#define __device__
+#endif
 #include <stdint.h>
 
 #include "../../include/reactranker_hip.h"
@@ -9,17 +14,21 @@
 #define RR_WAVE 64
 #define RR_NUM_CU 256   // MI355X: 8 XCDs x 32 CUs
 
+#if defined(__HIPCC__)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#endif
 
 #define RR_CHECK_ARG(cond) \
   do {                     \
     if (!(cond)) return RR_ERR_ARG; \
   } while (0)
 
+#if defined(__HIPCC__)
 static inline int rr_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? RR_OK : RR_ERR_LAUNCH;
 }
+#endif
 
 static inline bool rr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -79,6 +88,7 @@ __host__ __device__ static inline bool rr_keep(uint64_t seed, uint64_t index, ui
   return rr_hash_u32(seed, index) >= threshold;
 }
 
+#if defined(__HIPCC__)
 // torch.nn.Softplus(beta=1, threshold=20): x > 20 -> x, else log1p(exp(x)).
 __device__ static inline float rr_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ static inline float rr_softplus_grad(float x) { return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)); }
@@ -103,3 +113,4 @@ __device__ static inline float rr_wave_incl_scan(float v, int lane) {
   }
   return v;
 }
+#endif  // __HIPCC__

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from typing import Callable, Iterable, List, Optional, Sequence, Union
 
+import numpy as np
 import torch
 
 from . import loss as RL
@@ -20,6 +21,56 @@ from .utils import save_checkpoint
 NDCG_METRICS = ["NDCG@1", "NDCG@2", "NDCG@25%", "NDCG@all"]
 SUPPORTED_TASKS = ("mle", "listnet", "evidential_ranking", "gauss_regression", "mle_gaussian", "listnet_gauss",
                    "mle_regression", "listnet_regression", "regression")
+
+
+def standardize_targets(train_targets, val_targets, target_name: str = "ea", normalize_target=True, save_metric=None):
+    """Target standardisation and sign flip of the reference trainer (train/train_listwise.py:66-122), on arrays.
+
+    Activation energies ('ea' and every name other than 'lgk' / 'lgk_bi') rank the LOWEST value first, so their sign
+    is flipped; 'lgk' keeps its sign, 'lgk_bi' is passed through.  `normalize_target`: True -> z-score with the
+    training set's mean / population std (ddof=0); False -> sign only; a float f -> x * f / (max - min) of the
+    training set; a string 'lo,hi' -> min-max onto [lo, hi].  With an NDCG save metric the validation targets stay
+    raw (:117-120).  Returns (train_std, val_std, mean, std) - mean / std are what the checkpoint stores."""
+    tr = np.asarray(train_targets, np.float64)
+    va = np.asarray(val_targets, np.float64)
+    mean, std = float(tr.mean()), float(tr.std())                 # pandas .std(ddof=0)
+    if target_name == "lgk_bi":
+        f = lambda x: x                                           # noqa: E731
+    else:
+        sign = 1.0 if target_name == "lgk" else -1.0
+        if isinstance(normalize_target, float):
+            mx, mn = tr.max(), tr.min()
+            f = lambda x: sign * (x * normalize_target) / (mx - mn)                       # noqa: E731
+        elif isinstance(normalize_target, str):
+            mx, mn = tr.max(), tr.min()
+            lo, hi = (int(v) for v in normalize_target.split(","))
+            f = lambda x: sign * (x - mn) * (hi - lo) / (mx - mn) + lo                   # noqa: E731
+        elif normalize_target:
+            f = lambda x: sign * (x - mean) / std                                        # noqa: E731
+        else:
+            f = lambda x: sign * x                                                       # noqa: E731
+    val_std = va if save_metric in NDCG_METRICS else f(va)
+    return f(tr), val_std, mean, std
+
+
+def standardize_batches(train_batches, val_batches, target_name="ea", normalize_target=True, save_metric=None):
+    """standardize_targets over lists of packed batches: statistics from ALL training targets (the reference computes
+    them on the training DataFrame), new batch dicts with standardised float32 `targets`."""
+    def cat(bs):
+        return np.concatenate([np.asarray(torch.as_tensor(b["targets"]).cpu(), np.float64).reshape(-1) for b in bs]) \
+            if len(bs) else np.zeros(0)
+    tr, va, mean, std = standardize_targets(cat(train_batches), cat(val_batches), target_name, normalize_target, save_metric)
+
+    def split(bs, flat):
+        out, off = [], 0
+        for b in bs:
+            n = int(torch.as_tensor(b["targets"]).numel())
+            nb = dict(b)
+            nb["targets"] = torch.tensor(flat[off:off + n], dtype=torch.float32)
+            off += n
+            out.append(nb)
+        return out
+    return split(train_batches, tr), split(val_batches, va), mean, std
 
 
 def batch_loss(task_type: str, output, scope, targets, gpu, epoch: int = 0, epochs: int = 1, max_coeff: float = 1e-4):
@@ -49,13 +100,18 @@ def batch_loss(task_type: str, output, scope, targets, gpu, epoch: int = 0, epoc
 def train(model: torch.nn.Module, scheduler, train_batches: Union[Sequence, Callable[[int], Iterable]],
           val_batches: Sequence, path_checkpoints: Union[str, List[str], None], optimizer, epochs: int, seed: int, gpu: int,
           task_type: str = "mle", logger=None, save_metric: Optional[str] = None, max_coeff: float = 1e-4,
-          mean: float = 0.0, std: float = 1.0):
+          mean: float = 0.0, std: float = 1.0, target_name: Optional[str] = None, normalize_target=True):
     """Same control flow as the reference train(): fixed seed, per batch forward / loss / zero_grad / backward /
     optimizer.step / scheduler.step (train_listwise.py:287-290), validation with ranking_metrics after every epoch,
     checkpoint whenever the selected metric does not get worse (:310-350).  `train_batches` is a sequence, or a
     callable epoch -> iterable (the reference reshuffles with seed=epoch, :178).  Returns the per-epoch history."""
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
+    if target_name is not None:                       # raw targets: standardise / flip like the reference (:66-122)
+        if callable(train_batches):
+            raise ValueError("target standardisation needs the training batches as a sequence (statistics over all of them)")
+        train_batches, val_batches, mean, std = standardize_batches(list(train_batches), list(val_batches), target_name,
+                                                                     normalize_target, save_metric)
     model = model.cuda(gpu)
     # dropout streams: every forward draws a fresh stream seed from torch's generator (mpn._fresh_seed), which the
     # manual_seed above makes reproducible - like the reference, whose nn.Dropout advances that generator per call.

@@ -607,3 +607,34 @@ def test_ranknet_training_loop_both_algorithms():
         losses = [TP.factorized_training_loop(ep, model, opt, sch, batches, 1.0, algo, gpu=0) for ep in range(4)]
         assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0], (algo, losses)
         assert sch.current_step == 1 + 4 * len(batches)
+
+
+@pytest.mark.parametrize("task_type,save_metric", [("listnet", "all"), ("ranknet", None), ("evidential_ranking", "NDCG@all")])
+def test_kfold_driver_with_config_object(tmp_path, task_type, save_metric):
+    """reactranker_amd.main.run: the control flow of the reference's main.py / main_ranknet.py templates (per-fold
+    seeds, build_model, optimizer + NoamLR, train / run_train with target standardisation, test on the best checkpoint)."""
+    from reactranker_amd import main as M
+
+    def folds(i):
+        out = []
+        for part, nq in (("train", 6), ("val", 3), ("test", 3)):
+            qb = synth.make_queries(1000 * i + len(out), nq, 5, atoms_lo=5, atoms_hi=9)
+            raw = (-3.0 * qb.targets + 40.0).astype(np.float32)        # "activation energies": lower is better
+            out.append([dict(r=featurization.BatchMolGraph(qb.r_specs, K=4), p=featurization.BatchMolGraph(qb.p_specs, K=4),
+                             scope=qb.scope, targets=torch.tensor(raw), add=qb.add_features)])
+        return tuple(out)
+    cfg = M.Config(path=str(tmp_path / "run"), k_fold=2, total_epochs=2, batch_size=6, task_type=task_type,
+                   target_name="ea", save_metric=save_metric, add_features_dim=1,
+                   model=dict(hidden_size=32, mpnn_depth=2, mpnn_diff_depth=2, ffn_depth=2, use_bias=True, dropout=0.1,
+                              task_num=1, ffn_last_layer="with_softplus"))
+    scores = M.run(cfg, folds)
+    assert len(scores) == 2 and all(len(s) == 3 and all(0.0 <= v <= 1.0 for v in s) for s in scores)
+    if save_metric == "all":
+        for sub in ("T1", "T25_in_T25", "T25"):
+            assert os.path.exists(os.path.join(cfg.path, sub, "0.pt")) and os.path.exists(os.path.join(cfg.path, sub, "1.pt"))
+        st = torch.load(os.path.join(cfg.path, "T1", "1.pt"), weights_only=False)
+    else:
+        st = torch.load(os.path.join(cfg.path, "1.pt"), weights_only=False)
+    raw_all = np.concatenate([np.asarray(b["targets"]) for b in folds(1)[0]])
+    assert abs(st["data_scaler"]["means"] - float(raw_all.mean())) < 1e-4          # statistics of the RAW training targets
+    assert abs(st["data_scaler"]["stds"] - float(raw_all.std())) < 1e-4

@@ -248,3 +248,46 @@ def test_train_utils_match_reference_scheduler(golden_dir):
         assert TU.param_count(net) == int(z[f"c{i}.param_count"])
         i += 1
     assert i == 3
+
+
+def test_target_standardisation_matches_the_reference_trainers(golden_dir):
+    """tests/golden/standardize.npz holds what the reference's own train() (train_listwise.py:66-122) and run_train()
+    (run_train_pairwise.py:36-45) wrote into their DataFrames (tools/make_golden.py:gen_standardize)."""
+    import json
+    from reactranker_amd.run_train_pairwise import standardize_pairwise
+    from reactranker_amd.train_listwise import standardize_targets
+    d = np.load(f"{golden_dir}/standardize.npz")
+    seen = set()
+    for i in range(int(d["n_listwise"])):
+        c = json.loads(str(d[f"l{i}.cfg"]))
+        tr, va, mean, std = standardize_targets(d["train_raw"], d["val_raw"], c["target_name"], c["normalize_target"],
+                                                c["save_metric"])
+        assert np.allclose(tr, d[f"l{i}.train"], rtol=1e-12, atol=1e-12), c
+        assert np.allclose(va, d[f"l{i}.val"], rtol=1e-12, atol=1e-12), c
+        assert abs(mean - float(d["mean"])) < 1e-12 and abs(std - float(d["std"])) < 1e-12
+        seen.add((c["target_name"], str(c["normalize_target"])))
+    assert len(seen) == 12                                            # 3 target kinds x 4 normalisation modes
+    for j in range(2):
+        tr, va, _, _ = standardize_pairwise(d["train_raw"], d["val_raw"], str(d[f"p{j}.target_name"]))
+        assert np.allclose(tr, d[f"p{j}.train"], rtol=1e-12) and np.allclose(va, d[f"p{j}.val"], rtol=1e-12)
+
+
+def test_packer_under_address_sanitizer():
+    """no GPU sanitizer exists on this pool, so the HOST half of the C-ABI (the graph packer) is
+    built with g++ -fsanitize=address,undefined (`make asan`) and driven on ragged / empty / wide-K / corrupt batches
+    in a child process that preloads the sanitizer runtime."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
+        pytest.skip("no libasan runtime")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "reactranker_amd", "csrc"), "asan"], check=True, capture_output=True)
+    env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "asan_pack_check.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "no report" in r.stdout

@@ -503,6 +503,62 @@ def gen_train_utils():
     print("wrote train_utils.npz", [float(out["c0.lrs"][k]) for k in (0, 1, 40, 41, 200)])
 
 
+def gen_standardize():
+    """Target standardisation / sign flip of the reference trainers, produced by running the reference's OWN
+    train() (train/train_listwise.py:66-122) and run_train() (train/run_train_pairwise.py:36-45) with epochs=0:
+    the functions standardise, build their loss objects and return before the first epoch.  They deep-copy their
+    DataFrames, so the frames handed in answer __deepcopy__ with themselves and the 'std<target>' column the
+    reference writes can be read back.  (torch.utils.tensorboard is absent here: a module with a dummy
+    SummaryWriter stands in for the import only.)"""
+    import logging
+    import pandas as pd
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    from reactranker.train.train_listwise import train as ref_train
+    from reactranker.train.run_train_pairwise import run_train as ref_run_train
+
+    class KeepDF(pd.DataFrame):
+        @property
+        def _constructor(self):
+            return KeepDF
+
+        def __deepcopy__(self, memo):
+            return self
+
+    rng = np.random.default_rng(7)
+    tr = rng.normal(12.0, 4.0, 23)
+    va = rng.normal(11.0, 5.0, 9)
+    log = logging.getLogger("golden")
+    out = {"train_raw": tr, "val_raw": va}
+    net = torch.nn.Linear(1, 1)
+    i = 0
+    for target_name in ("ea", "lgk", "lgk_bi"):
+        for norm in (True, False, 0.5, "1,5"):
+            for save_metric in (None, "NDCG@1"):
+                dtr = KeepDF({"rsmi": [f"r{k % 5}" for k in range(len(tr))], target_name: tr.copy()})
+                dva = KeepDF({"rsmi": [f"r{k % 3}" for k in range(len(va))], target_name: va.copy()})
+                ref_train(net, None, dtr, dva, None, None, 0, None, 2, 0, None, task_type="mle", writer=None, logger=log,
+                          target_name=target_name, save_metric=save_metric, normalize_target=norm)
+                out[f"l{i}.cfg"] = np.array(json.dumps(dict(target_name=target_name, normalize_target=norm,
+                                                            save_metric=save_metric)))
+                out[f"l{i}.train"] = np.asarray(dtr["std" + target_name], np.float64)
+                out[f"l{i}.val"] = np.asarray(dva["std" + target_name], np.float64)
+                i += 1
+    out["n_listwise"] = np.int64(i)
+    for j, target_name in enumerate(("ea", "lgk")):
+        dtr = KeepDF({"rsmi": [f"r{k % 5}" for k in range(len(tr))], target_name: tr.copy()})
+        dva = KeepDF({"rsmi": [f"r{k % 3}" for k in range(len(va))], target_name: va.copy()})
+        ref_run_train(net, None, dtr, dva, None, None, 0, None, 2, 0, None, "sum_session", "baseline", None, log, None,
+                      target_name)
+        out[f"p{j}.target_name"] = np.array(target_name)
+        out[f"p{j}.train"] = np.asarray(dtr["std" + target_name], np.float64)
+        out[f"p{j}.val"] = np.asarray(dva["std" + target_name], np.float64)
+    out["mean"], out["std"] = np.float64(tr.mean()), np.float64(tr.std())
+    np.savez_compressed(os.path.join(OUT, "standardize.npz"), **out)
+    print("wrote standardize.npz:", i, "listwise variants, 2 pairwise;", out["l0.train"][:3], out["l2.train"][:3])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -516,3 +572,4 @@ if __name__ == "__main__":
     gen_metrics()
     gen_eval_metrics()
     gen_train_utils()
+    gen_standardize()
