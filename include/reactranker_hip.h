@@ -357,6 +357,72 @@ int rr_derive_tables(const int32_t* a2b, const int32_t* b2a, const int32_t* b2re
                      int32_t* a2a, int32_t* a2b_rev_t, int32_t* b2t, int32_t* a2a_t,
                      float* npad, int32_t* atom2mol);
 
+/* ------------------------------------------------------------------ whole-model step plans --- */
+/* ReactionModel.forward (models/base_model.py:150-171: encoder on reactants and products, p_h - r_h, diff encoder,
+ * readout, FFN + head) and its explicit backward as ONE call each: the host-side orchestration of the per-op entry
+ * points above (operand wiring, dropout stream seeds, the weight-gradient / reactant-encoder streams and their events)
+ * for hosts that should not - or cannot - issue ~140 launches per training step themselves.  All activations live in ONE
+ * caller-provided workspace whose layout is a pure function of (model, step): rr_reaction_backward re-derives every
+ * saved address, the library keeps no state between the two calls.  Requirements: H % 4 == 0, 16-byte aligned rows
+ * (what the packer produces); other shapes use the per-op entry points.  Device pointers unless noted.
+ * The gradient all-reduce of a data-parallel job is deliberately NOT part of this ABI: the communicator belongs to the
+ * launcher (torch.distributed / RCCL); a step is forward, loss kernel, backward, then the host's collective. */
+#define RR_MAX_FFN 8
+
+typedef struct rr_graph {             /* a packed batch resident in HBM (arrays of rr_pack_graphs / rr_derive_*) */
+  int64_t nA, nB, M;
+  int K, Kb;
+  const float* f_atoms;  int64_t ld_fa;
+  const float* f_bonds;  int64_t ld_fb;    /* may be NULL for rr_step.r in RR_STEP_PREFIX mode (only u.f_bonds is read) */
+  const int32_t *a2b, *b2a, *b2revb, *a2a, *a_scope, *b2t, *a2a_t, *atom2mol, *b2b_t;
+  const float *npad, *npad_b;
+  const float* fb_sum;   int64_t ld_fbs;   /* sum_k f_bonds[a2b[a,k]] [nA, ld_fbs] (input-only; needed when diff_depth > 1) */
+} rr_graph;
+
+typedef struct rr_linear_w {          /* one nn.Linear: weight [out, in] row-major with row stride ldw, bias [out] or NULL */
+  const float* w;
+  const float* b;
+  int out, in;
+  int64_t ldw;
+} rr_linear_w;
+
+typedef struct rr_model {
+  int H, depth, diff_depth, n_ffn, head;          /* head: rr_head of the FFN output (0 = none) */
+  int atom_fdim, bond_fdim;                       /* 61, 83 (= 61 + 22) */
+  rr_linear_w enc_wi, enc_wh, enc_wo;             /* MPN     (models/mpn.py:40-59);  enc_wh unused when depth == 1 */
+  rr_linear_w dif_wi, dif_wh, dif_wo;             /* MPNDiff (models/mpn.py:161-168) */
+  rr_linear_w ffn[RR_MAX_FFN];                    /* FFN Linear layers in order (models/base_model.py:32-57) */
+} rr_model;
+
+enum { RR_STEP_PLAIN = 0,    /* encoder(r) on the full reactant batch */
+       RR_STEP_DEDUP = 1,    /* dropout inactive: `r` holds the DISTINCT reactants, amap / amap_t map product atoms to them */
+       RR_STEP_PREFIX = 2 }; /* train mode: `u` holds the distinct reactants, only the deterministic prefix is shared */
+enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2 };
+
+typedef struct rr_step {
+  rr_graph p, r, u;
+  int mode;
+  const int32_t* amap;    const int32_t* amap_t;  int amap_t_cols;    /* RR_STEP_DEDUP */
+  const int32_t* bmap;    const int32_t* bmap_t;  int bmap_t_cols;    /* RR_STEP_PREFIX */
+  const float* feat;      int F;                  /* add_features [M, F] or NULL */
+  float drop_p;           uint64_t seed;          /* dropout rate in effect (0 in eval mode) and the step's stream seed */
+  void* workspace;        size_t workspace_bytes; /* >= rr_reaction_workspace_bytes(model, step); kept until backward */
+  float* out;                                     /* [M, ffn[n_ffn-1].out] */
+} rr_step;
+
+enum { RR_G_ENC_WI = 0, RR_G_ENC_WH, RR_G_ENC_WO, RR_G_DIF_WI, RR_G_DIF_WH, RR_G_DIF_WO, RR_G_FFN0 };
+typedef struct rr_grads {             /* gradient buffers, same shapes / row strides as the parameters (dense: ld = in) */
+  float* w[RR_G_FFN0 + RR_MAX_FFN];
+  float* b[RR_G_FFN0 + RR_MAX_FFN];   /* NULL where the layer has no bias */
+} rr_grads;
+
+/* sizeof of the four plan structs as compiled, so a binding can verify its layout. */
+void rr_abi_plan_struct_sizes(size_t* graph, size_t* model, size_t* step, size_t* grads);
+size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step);
+int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, rr_stream_t stream);
+int rr_reaction_backward(const rr_model* model, const rr_step* step, const float* dout, const rr_grads* grads, int flags,
+                         rr_stream_t stream);
+
 /* Bond-to-bond backward table (HOST pointers), derived from the tables above.  The adjoint of
  *   message[b] = a_message[b2a[b]] - message[b2revb[b]],  a_message[a] = sum_k message[a2b[a,k]]   (models/mpn.py:89-92)
  * is  d message[b] = sum of d m_in over the bonds leaving atom target(b), minus d m_in[rev(b)]; rev(b) is one of those

@@ -55,6 +55,52 @@ class WgradArgs(C.Structure):
     ]
 
 
+RR_MAX_FFN = 8
+RR_G_FFN0 = 6
+RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
+RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM = 1, 2
+
+
+class Graph(C.Structure):
+    _fields_ = [
+        ("nA", i64), ("nB", i64), ("M", i64), ("K", i32), ("Kb", i32),
+        ("f_atoms", c_f32p), ("ld_fa", i64), ("f_bonds", c_f32p), ("ld_fb", i64),
+        ("a2b", c_i32p), ("b2a", c_i32p), ("b2revb", c_i32p), ("a2a", c_i32p), ("a_scope", c_i32p), ("b2t", c_i32p),
+        ("a2a_t", c_i32p), ("atom2mol", c_i32p), ("b2b_t", c_i32p),
+        ("npad", c_f32p), ("npad_b", c_f32p),
+        ("fb_sum", c_f32p), ("ld_fbs", i64),
+    ]
+
+
+class LinearW(C.Structure):
+    _fields_ = [("w", c_f32p), ("b", c_f32p), ("out", i32), ("in_", i32), ("ldw", i64)]
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("H", i32), ("depth", i32), ("diff_depth", i32), ("n_ffn", i32), ("head", i32), ("atom_fdim", i32), ("bond_fdim", i32),
+        ("enc_wi", LinearW), ("enc_wh", LinearW), ("enc_wo", LinearW),
+        ("dif_wi", LinearW), ("dif_wh", LinearW), ("dif_wo", LinearW),
+        ("ffn", LinearW * RR_MAX_FFN),
+    ]
+
+
+class Step(C.Structure):
+    _fields_ = [
+        ("p", Graph), ("r", Graph), ("u", Graph), ("mode", i32),
+        ("amap", c_i32p), ("amap_t", c_i32p), ("amap_t_cols", i32),
+        ("bmap", c_i32p), ("bmap_t", c_i32p), ("bmap_t_cols", i32),
+        ("feat", c_f32p), ("F", i32),
+        ("drop_p", f32), ("seed", u64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("out", c_f32p),
+    ]
+
+
+class Grads(C.Structure):
+    _fields_ = [("w", c_f32p * (RR_G_FFN0 + RR_MAX_FFN)), ("b", c_f32p * (RR_G_FFN0 + RR_MAX_FFN))]
+
+
 _SIGS = {
     "rr_strerror": (C.c_char_p, [i32]),
     "rr_version": (i32, []),
@@ -105,6 +151,10 @@ _SIGS = {
                              C.c_void_p, C.c_void_p, i32, C.c_void_p, i64, C.c_void_p, i64, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "rr_abi_plan_struct_sizes": (None, [C.POINTER(C.c_size_t)] * 4),
+    "rr_reaction_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(Step)]),
+    "rr_reaction_forward": (i32, [C.POINTER(Model), C.POINTER(Step), i32, c_stream]),
+    "rr_reaction_backward": (i32, [C.POINTER(Model), C.POINTER(Step), c_f32p, C.POINTER(Grads), i32, c_stream]),
     "rr_derive_bond_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, i32,
                                     C.c_void_p, C.c_void_p]),
     "rr_derive_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, C.c_void_p, i64, C.c_void_p,
@@ -137,6 +187,10 @@ def lib():
         l.rr_abi_struct_sizes(C.byref(sl), C.byref(sw))
         if sl.value != C.sizeof(LinearArgs) or sw.value != C.sizeof(WgradArgs):
             raise RuntimeError("reactranker_amd: ctypes struct layout differs from the compiled header")
+        sz = [C.c_size_t() for _ in range(4)]
+        l.rr_abi_plan_struct_sizes(*[C.byref(x) for x in sz])
+        if [x.value for x in sz] != [C.sizeof(Graph), C.sizeof(Model), C.sizeof(Step), C.sizeof(Grads)]:
+            raise RuntimeError("reactranker_amd: ctypes plan struct layout differs from the compiled header")
         _lib = l
     return _lib
 

@@ -1,0 +1,777 @@
+// Whole-model step plans: ReactionModel.forward (reference models/base_model.py:150-171) and its explicit backward as
+// ONE C-ABI call each.  The kernels are the library's own entry points (rr_linear_f32, rr_gather_sum_f32, ...); what
+// lives here is the host-side orchestration the Python mirror used to do launch by launch (~140 ctypes calls and
+// ~4 ms of interpreter time per training step): operand wiring, dropout stream seeds, the weight-gradient stream and
+// the reactant-encoder stream with their events, and a bump allocator over ONE caller-provided workspace whose layout
+// is a pure function of (model, step) - so the backward call re-derives every saved activation's address and the
+// library keeps no state between calls.  A non-Python host drives training with these two calls plus a loss kernel.
+//
+// Scope: hidden sizes with H % 4 == 0 (every operand 16-byte addressable: the straight-line kernels); other shapes
+// stay on the per-op entry points.  Numerics, kernel order and dropout streams are exactly those of
+// reactranker_amd/functions.py (mpn_forward / mpn_forward_shared / mpndiff_forward / ffn_forward and their
+// adjoints), which the parity tests compare bit for bit.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rr_common.h"
+
+namespace {
+
+constexpr int ATOM_FDIM = 61;
+
+inline uint64_t site_seed(uint64_t seed, uint64_t site) {
+  return seed * 0x9E3779B97F4A7C15ull + site * 0xD1B54A32D192ED03ull;
+}
+inline int64_t r4(int64_t n) { return (n + 3) / 4 * 4; }
+
+struct Arena {                       // bump allocator over the caller's workspace (or a dry run that only measures)
+  char* base;
+  size_t off, cap;
+  bool overflow;
+  float* f(int64_t rows, int64_t cols) {
+    const size_t bytes = (static_cast<size_t>(rows < 1 ? 1 : rows) * static_cast<size_t>(cols) * sizeof(float) + 255) & ~size_t(255);
+    const size_t at = off;
+    off += bytes;
+    if (base == nullptr) return nullptr;
+    if (off > cap) { overflow = true; return reinterpret_cast<float*>(base); }
+    return reinterpret_cast<float*>(base + at);
+  }
+};
+
+struct Streams {
+  hipStream_t main, side, aux;
+};
+
+// per-device side / aux streams (created once; non-blocking so they never synchronise with the null stream)
+struct DevStreams { bool init; hipStream_t side, aux; };
+DevStreams g_streams[64];
+
+int get_streams(hipStream_t main, Streams* s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RR_ERR_LAUNCH;
+  DevStreams& d = g_streams[dev];
+  if (!d.init) {
+    if (hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking) != hipSuccess) return RR_ERR_LAUNCH;
+    if (hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking) != hipSuccess) return RR_ERR_LAUNCH;
+    d.init = true;
+  }
+  s->main = main;
+  s->side = d.side;
+  s->aux = d.aux;
+  return RR_OK;
+}
+
+// `waiter` waits for everything enqueued on `signaller` so far
+int stream_wait(hipStream_t waiter, hipStream_t signaller) {
+  if (waiter == signaller) return RR_OK;
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return RR_ERR_LAUNCH;
+  int st = RR_OK;
+  if (hipEventRecord(e, signaller) != hipSuccess || hipStreamWaitEvent(waiter, e, 0) != hipSuccess) st = RR_ERR_LAUNCH;
+  (void)hipEventDestroy(e);           // destruction is deferred by the runtime until the event has completed
+  return st;
+}
+
+struct Ctx {
+  bool launch;                        // false: layout pass only (no kernel is enqueued)
+  int status;
+  Arena ar;
+  Streams s;
+  bool use_side, use_aux;
+  void fail(int st) { if (status == RR_OK && st != RR_OK) status = st; }
+};
+
+#define RR_TRY(ctx, expr)                                                                         \
+  do {                                                                                            \
+    if ((ctx).launch && (ctx).status == RR_OK) {                                                  \
+      (ctx).fail(expr);                                                                           \
+      if ((ctx).status != RR_OK && getenv("RR_PLAN_DEBUG"))                                       \
+        fprintf(stderr, "[rr plan] status %d at plan.hip:%d: %s\n", (ctx).status, __LINE__, #expr); \
+    }                                                                                             \
+  } while (0)
+
+rr_linear_args LA(int64_t M, int N) {
+  rr_linear_args a;
+  memset(&a, 0, sizeof(a));
+  a.M = M;
+  a.N = N;
+  a.mask_scale = 1.0f;
+  a.w_packed = 1;
+  return a;
+}
+
+// packed weight [rows, r16(k1)+r16(k2)] of W[:, c0 : c0+k1+k2] (transpose = 0) or of its transpose
+struct Packed { const float* w; int64_t ld; };
+Packed pack(Ctx& c, const rr_linear_w& L, int transpose, int rows, int c0, int k1, int k2, hipStream_t st) {
+  Packed p;
+  p.ld = rr_packed_weight_ld(k1, k2);
+  float* dst = c.ar.f(rows, p.ld);
+  p.w = dst;
+  RR_TRY(c, rr_pack_weight_f32(L.w, L.ldw, transpose, rows, c0, k1, k2, dst, st));
+  return p;
+}
+
+void set_w(rr_linear_args& a, const Packed& p) { a.w = p.w; a.ldw = p.ld; a.w_packed = 1; }
+
+void gather_sum(Ctx& c, const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K, int H,
+                float* out, int64_t ld_out, hipStream_t st, const float* part = nullptr, int64_t n_part = 0, int64_t ld_part = 0) {
+  if (part) RR_TRY(c, rr_gather_sum_padrow_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, st));
+  else RR_TRY(c, rr_gather_sum_f32(src, n_src, ld_src, idx, n_out, K, H, out, ld_out, st));
+}
+
+// weight gradient on the side stream: waits for the main stream's work so far (its operands), returns immediately
+void wgrad(Ctx& c, rr_wgrad_args& a) {
+  const size_t wb = rr_linear_wgrad_workspace_bytes(a.M, a.N, a.k1 + a.k2);
+  a.workspace = c.ar.f(1, static_cast<int64_t>((wb + 3) / 4));
+  a.workspace_bytes = wb;
+  if (!c.launch || c.status != RR_OK) return;
+  hipStream_t st = c.use_side ? c.s.side : c.s.main;
+  if (c.use_side) c.fail(stream_wait(c.s.side, c.s.main));
+  c.fail(rr_linear_wgrad_f32(&a, st));
+  if (c.status != RR_OK && getenv("RR_PLAN_DEBUG"))
+    fprintf(stderr, "[rr plan] wgrad status %d: M %lld N %d k1 %d k2 %d ws %zu\n", c.status, (long long)a.M, a.N, a.k1, a.k2, wb);
+}
+
+rr_wgrad_args WA(int64_t M, int N, const float* dy, int64_t ld_dy, float* dw, int64_t ld_dw, float* dbias, int accumulate) {
+  rr_wgrad_args a;
+  memset(&a, 0, sizeof(a));
+  a.M = M; a.N = N; a.dy = dy; a.ld_dy = ld_dy; a.dw = dw; a.ld_dw = ld_dw; a.dbias = dbias; a.accumulate = accumulate;
+  a.mask_scale = 1.0f;
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------------ saved state
+constexpr int MAXD = 16;             // message-passing depth supported by a plan
+
+struct EncSaved {                    // mpn_forward / mpn_forward_shared
+  float* msgs[MAXD];                 // [nB, H] each (shared mode: msgs[0] unused)
+  float* amsgs[MAXD];                // [nA, H]
+  float* a_last;
+  float* h;                          // [nA, H] atom hiddens (output)
+  float *msg0_u, *a0_u;              // shared prefix (distinct molecules)
+};
+struct DiffSaved {
+  float* msgs[MAXD];
+  float* amsgs[MAXD];
+  float* a_last;
+  float* hid;
+  float* vecs; int64_t ld_vecs;      // [M, r4(H+F)]
+};
+struct FfnSaved {
+  float* hs[RR_MAX_FFN + 1];         // hs[0] = vecs
+  int64_t ld_hs[RR_MAX_FFN + 1];
+  float* raw;                        // [M, n_out]
+};
+struct PackedW {
+  Packed enc_wi, enc_wh, enc_wo, dif_wi, dif_wh, dif_wo, ffn[RR_MAX_FFN];
+};
+struct Plan {
+  PackedW pk;
+  EncSaved r, p;
+  DiffSaved d;
+  FfnSaved f;
+  size_t fwd_end;
+};
+
+// ------------------------------------------------------------------------------------------------ forward pieces
+// MPN.forward, return_atom_hiddens=True (models/mpn.py:61-108)
+void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk, float p, uint64_t seed, EncSaved& S,
+                 hipStream_t st) {
+  const int H = m.H, depth = m.depth, FB = m.bond_fdim;
+  float* inp = c.ar.f(g.nB, H);
+  S.msgs[0] = c.ar.f(g.nB, H);
+  {
+    rr_linear_args a = LA(g.nB, H);
+    a.a1 = g.f_bonds; a.lda1 = g.ld_fb; a.k1 = FB;
+    set_w(a, pk.enc_wi); a.bias = m.enc_wi.b; a.act = RR_ACT_RELU;
+    a.c = S.msgs[0]; a.ldc = H; a.c_pre = inp; a.ld_pre = H;
+    RR_TRY(c, rr_linear_f32(&a, st));                                                   // :80-81
+  }
+  for (int it = 0; it < depth - 1; ++it) {                                              // :84
+    S.amsgs[it] = c.ar.f(g.nA, H);
+    gather_sum(c, S.msgs[it], g.nB, H, g.a2b, g.nA, g.K, H, S.amsgs[it], H, st);       // :89-90
+    S.msgs[it + 1] = c.ar.f(g.nB, H);
+    rr_linear_args a = LA(g.nB, H);
+    a.a1 = S.amsgs[it]; a.lda1 = H; a.k1 = H; a.a1_idx = g.b2a;
+    a.a1_sub = S.msgs[it]; a.lda1_sub = H; a.a1_sub_idx = g.b2revb;
+    set_w(a, pk.enc_wh); a.bias = m.enc_wh.b; a.residual = inp; a.ldr = H; a.act = RR_ACT_RELU;
+    a.drop_p = p; a.drop_seed = site_seed(seed, it);
+    a.c = S.msgs[it + 1]; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));                                                   // :91-97
+  }
+  S.a_last = c.ar.f(g.nA, H);
+  gather_sum(c, S.msgs[depth - 1], g.nB, H, g.a2b, g.nA, g.K, H, S.a_last, H, st);     // :101-102
+  S.h = c.ar.f(g.nA, H);
+  rr_linear_args a = LA(g.nA, H);
+  a.a1 = g.f_atoms; a.lda1 = g.ld_fa; a.k1 = m.atom_fdim; a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
+  set_w(a, pk.enc_wo); a.bias = m.enc_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 1000);
+  a.c = S.h; a.ldc = H;
+  RR_TRY(c, rr_linear_f32(&a, st));                                                     // :103-105
+}
+
+// the same for a batch whose molecules repeat: the deterministic prefix runs once per distinct molecule
+void mpn_forward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_graph& g, const int32_t* bmap,
+                        const PackedW& pk, float p, uint64_t seed, EncSaved& S, hipStream_t st) {
+  const int H = m.H, depth = m.depth, FB = m.bond_fdim;
+  float* inp_u = c.ar.f(gu.nB, H);
+  S.msg0_u = c.ar.f(gu.nB, H);
+  {
+    rr_linear_args a = LA(gu.nB, H);
+    a.a1 = gu.f_bonds; a.lda1 = gu.ld_fb; a.k1 = FB;
+    set_w(a, pk.enc_wi); a.bias = m.enc_wi.b; a.act = RR_ACT_RELU;
+    a.c = S.msg0_u; a.ldc = H; a.c_pre = inp_u; a.ld_pre = H;
+    RR_TRY(c, rr_linear_f32(&a, st));
+  }
+  S.a0_u = c.ar.f(gu.nA, H);
+  gather_sum(c, S.msg0_u, gu.nB, H, gu.a2b, gu.nA, gu.K, H, S.a0_u, H, st);
+  float* z1_u = c.ar.f(gu.nB, H);
+  {
+    rr_linear_args a = LA(gu.nB, H);
+    a.a1 = S.a0_u; a.lda1 = H; a.k1 = H; a.a1_idx = gu.b2a;
+    a.a1_sub = S.msg0_u; a.lda1_sub = H; a.a1_sub_idx = gu.b2revb;
+    set_w(a, pk.enc_wh); a.bias = m.enc_wh.b; a.residual = inp_u; a.ldr = H; a.act = RR_ACT_RELU;
+    a.c = z1_u; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));                                                   // pre-dropout, shared
+  }
+  S.msgs[0] = nullptr;
+  S.msgs[1] = c.ar.f(g.nB, H);
+  RR_TRY(c, rr_gather_dropout_f32(z1_u, gu.nB, H, bmap, g.nB, H, p, site_seed(seed, 0), S.msgs[1], H, st));   // per-copy masks
+  for (int it = 1; it < depth - 1; ++it) {
+    S.amsgs[it] = c.ar.f(g.nA, H);
+    gather_sum(c, S.msgs[it], g.nB, H, g.a2b, g.nA, g.K, H, S.amsgs[it], H, st);
+    S.msgs[it + 1] = c.ar.f(g.nB, H);
+    rr_linear_args a = LA(g.nB, H);
+    a.a1 = S.amsgs[it]; a.lda1 = H; a.k1 = H; a.a1_idx = g.b2a;
+    a.a1_sub = S.msgs[it]; a.lda1_sub = H; a.a1_sub_idx = g.b2revb;
+    set_w(a, pk.enc_wh); a.bias = m.enc_wh.b; a.residual = inp_u; a.ldr = H; a.residual_idx = bmap; a.act = RR_ACT_RELU;
+    a.drop_p = p; a.drop_seed = site_seed(seed, it);
+    a.c = S.msgs[it + 1]; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));
+  }
+  S.a_last = c.ar.f(g.nA, H);
+  gather_sum(c, S.msgs[depth - 1], g.nB, H, g.a2b, g.nA, g.K, H, S.a_last, H, st);
+  S.h = c.ar.f(g.nA, H);
+  rr_linear_args a = LA(g.nA, H);
+  a.a1 = g.f_atoms; a.lda1 = g.ld_fa; a.k1 = m.atom_fdim; a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
+  set_w(a, pk.enc_wo); a.bias = m.enc_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 1000);
+  a.c = S.h; a.ldc = H;
+  RR_TRY(c, rr_linear_f32(&a, st));
+}
+
+// MPNDiff.forward (models/mpn.py:170-240): atom_features = x - x_sub[x_sub_idx]
+void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk, float p, uint64_t seed, const float* x,
+                     const float* x_sub, const int32_t* x_sub_idx, const float* feat, int F, uint64_t out_seed, DiffSaved& S,
+                     hipStream_t st) {
+  const int H = m.H, depth = m.diff_depth, FB = m.bond_fdim;
+  float* inp = c.ar.f(g.nA, H);
+  S.msgs[0] = c.ar.f(g.nA, H);
+  {
+    rr_linear_args a = LA(g.nA, H);
+    a.a1 = x; a.lda1 = H; a.k1 = H; a.a1_sub = x_sub; a.lda1_sub = H; a.a1_sub_idx = x_sub_idx;
+    set_w(a, pk.dif_wi); a.bias = m.dif_wi.b; a.act = RR_ACT_RELU;
+    a.drop_p = depth == 0 ? p : 0.f; a.drop_seed = site_seed(seed, 2000);              // :221 (depth 0: dropout(message))
+    a.c = S.msgs[0]; a.ldc = H; a.c_pre = inp; a.ld_pre = H;
+    RR_TRY(c, rr_linear_f32(&a, st));                                                   // :194-195
+  }
+  if (depth > 0) {
+    for (int it = 0; it < depth - 1; ++it) {                                            // :199
+      S.amsgs[it] = c.ar.f(g.nA, H);
+      gather_sum(c, S.msgs[it], g.nA, H, g.a2a, g.nA, g.K, H, S.amsgs[it], H, st);     // :201
+      S.msgs[it + 1] = c.ar.f(g.nA, H);
+      rr_linear_args a = LA(g.nA, H);
+      a.a1 = S.amsgs[it]; a.lda1 = H; a.k1 = H; a.a2 = g.fb_sum; a.lda2 = g.ld_fbs; a.k2 = FB;
+      set_w(a, pk.dif_wh); a.bias = m.dif_wh.b; a.residual = inp; a.ldr = H; a.act = RR_ACT_RELU;
+      a.drop_p = p; a.drop_seed = site_seed(seed, 2001 + it);
+      a.c = S.msgs[it + 1]; a.ldc = H;
+      RR_TRY(c, rr_linear_f32(&a, st));                                                 // :202-213
+    }
+    S.a_last = c.ar.f(g.nA, H);
+    gather_sum(c, S.msgs[depth - 1], g.nA, H, g.a2a, g.nA, g.K, H, S.a_last, H, st);   // :215-216
+    S.hid = c.ar.f(g.nA, H);
+    rr_linear_args a = LA(g.nA, H);
+    a.a1 = x; a.lda1 = H; a.k1 = H; a.a1_sub = x_sub; a.lda1_sub = H; a.a1_sub_idx = x_sub_idx;
+    a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
+    set_w(a, pk.dif_wo); a.bias = m.dif_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 3000);
+    a.c = S.hid; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));                                                   // :217-219
+  } else {
+    S.a_last = nullptr;
+    S.hid = S.msgs[0];
+  }
+  S.ld_vecs = r4(H + F);
+  S.vecs = c.ar.f(g.M, S.ld_vecs);
+  RR_TRY(c, rr_segment_mean_fwd_f32(S.hid, H, g.a_scope, g.M, H, feat, F, p, out_seed, S.vecs, S.ld_vecs, st));   // :224-238
+}
+
+void ffn_forward(Ctx& c, const rr_model& m, const PackedW& pk, int64_t M, float p, uint64_t seed, const float* x, int64_t ldx,
+                 float* out, FfnSaved& S, hipStream_t st) {
+  S.hs[0] = const_cast<float*>(x);
+  S.ld_hs[0] = ldx;
+  for (int li = 0; li < m.n_ffn - 1; ++li) {
+    const rr_linear_w& L = m.ffn[li];
+    S.ld_hs[li + 1] = r4(L.out);
+    S.hs[li + 1] = c.ar.f(M, S.ld_hs[li + 1]);
+    rr_linear_args a = LA(M, L.out);
+    a.a1 = S.hs[li]; a.lda1 = S.ld_hs[li]; a.k1 = L.in;
+    set_w(a, pk.ffn[li]); a.bias = L.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 4000 + li);
+    a.c = S.hs[li + 1]; a.ldc = S.ld_hs[li + 1];
+    RR_TRY(c, rr_linear_f32(&a, st));
+  }
+  const rr_linear_w& L = m.ffn[m.n_ffn - 1];
+  S.raw = m.head == 0 ? out : c.ar.f(M, L.out);
+  rr_linear_args a = LA(M, L.out);
+  a.a1 = S.hs[m.n_ffn - 1]; a.lda1 = S.ld_hs[m.n_ffn - 1]; a.k1 = L.in;
+  set_w(a, pk.ffn[m.n_ffn - 1]); a.bias = L.b;
+  a.c = S.raw; a.ldc = L.out;
+  RR_TRY(c, rr_linear_f32(&a, st));
+  if (m.head != 0) RR_TRY(c, rr_head_fwd_f32(S.raw, M, L.out, m.head, out, st));
+}
+
+void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
+  const int H = m.H;
+  const float p = s.drop_p;
+  hipStream_t main = c.s.main;
+  // packed weights (shared by both encoder passes): once, on the main stream
+  P.pk.enc_wi = pack(c, m.enc_wi, 0, H, 0, m.bond_fdim, 0, main);
+  if (m.depth > 1) P.pk.enc_wh = pack(c, m.enc_wh, 0, H, 0, H, 0, main);
+  P.pk.enc_wo = pack(c, m.enc_wo, 0, H, 0, m.atom_fdim, H, main);
+  hipStream_t rs = c.use_aux ? c.s.aux : main;
+  if (c.launch && c.use_aux) c.fail(stream_wait(c.s.aux, main));
+  const uint64_t s_r = site_seed(s.seed, 1), s_p = site_seed(s.seed, 2);
+  if (s.mode == RR_STEP_PREFIX) mpn_forward_shared(c, m, s.u, s.r, s.bmap, P.pk, p, s_r, P.r, rs);
+  else mpn_forward(c, m, s.r, P.pk, p, s_r, P.r, rs);
+  mpn_forward(c, m, s.p, P.pk, p, s_p, P.p, main);
+  if (c.launch && c.use_aux) c.fail(stream_wait(main, c.s.aux));
+  P.pk.dif_wi = pack(c, m.dif_wi, 0, H, 0, H, 0, main);
+  if (m.diff_depth > 1) P.pk.dif_wh = pack(c, m.dif_wh, 0, H, 0, H, m.bond_fdim, main);
+  if (m.diff_depth > 0) P.pk.dif_wo = pack(c, m.dif_wo, 0, H, 0, H, H, main);
+  mpndiff_forward(c, m, s.p, P.pk, p, site_seed(s.seed, 3), P.p.h, P.r.h, s.mode == RR_STEP_DEDUP ? s.amap : nullptr,
+                  s.feat, s.F, site_seed(s.seed, 4), P.d, main);
+  for (int li = 0; li < m.n_ffn; ++li) P.pk.ffn[li] = pack(c, m.ffn[li], 0, m.ffn[li].out, 0, m.ffn[li].in, 0, main);
+  ffn_forward(c, m, P.pk, s.p.M, p, site_seed(s.seed, 5), P.d.vecs, P.d.ld_vecs, s.out, P.f, main);
+  P.fwd_end = c.ar.off;
+}
+
+// ------------------------------------------------------------------------------------------------ backward pieces
+struct EncGrads { float *wi, *bi, *wh, *bh, *wo, *bo; };
+
+// d message = adjoint of the bond message (one gather over b2b_t; row 0 from the GEMM's weighted column sums)
+float* bond_adjoint(Ctx& c, const rr_graph& g, int H, const float* d_min, const float* part, hipStream_t st) {
+  float* d_msg = c.ar.f(g.nB, H);
+  gather_sum(c, d_min, g.nB, H, g.b2b_t, g.nB, g.Kb, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nB), r4(H));
+  return d_msg;
+}
+
+// adjoint of mpn_forward; accumulate = the gradient buffers already hold the other encoder pass
+void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk, const Packed& wh_t, const Packed& wo_t,
+                  float p, const EncSaved& S, const float* dH, float sign, const EncGrads& G, int accumulate) {
+  const int H = m.H, depth = m.depth;
+  const float ks = 1.0f / (1.0f - p);
+  hipStream_t st = c.s.main;
+  float* dz_o = c.ar.f(g.nA, H);
+  float* d_a = c.ar.f(g.nA, H);
+  float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
+  {
+    rr_linear_args a = LA(g.nA, H);
+    a.a1 = dH; a.lda1 = H; a.k1 = H; a.a_mask = S.h; a.ld_mask = H; a.mask_scale = sign * ks;
+    a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_t);
+    a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
+    a.c = d_a; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));
+  }
+  {
+    rr_wgrad_args w = WA(g.nA, H, dz_o, H, G.wo, m.enc_wo.in, G.bo, accumulate);
+    w.x1 = g.f_atoms; w.ldx1 = g.ld_fa; w.k1 = m.atom_fdim; w.x2 = S.a_last; w.ldx2 = H; w.k2 = H;
+    wgrad(c, w);
+  }
+  float* d_msg = c.ar.f(g.nB, H);
+  gather_sum(c, d_a, g.nA, H, g.b2t, g.nB, 1, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nA), r4(H));
+  const float* dzs[MAXD];
+  int ndz = 0;
+  for (int it = depth - 2; it >= 0; --it) {
+    float* dz = c.ar.f(g.nB, H);
+    float* d_min = c.ar.f(g.nB, H);
+    float* partb = c.ar.f(rr_linear_colsum_rows(g.nB), r4(H));
+    rr_linear_args a = LA(g.nB, H);
+    a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.ld_mask = H; a.mask_scale = ks;
+    a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
+    a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
+    a.c = d_min; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));
+    rr_wgrad_args w = WA(g.nB, H, dz, H, G.wh, H, G.bh, (accumulate || it != depth - 2) ? 1 : 0);
+    w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x1_idx = g.b2a; w.x1_sub = S.msgs[it]; w.ldx1_sub = H; w.x1_sub_idx = g.b2revb;
+    wgrad(c, w);
+    dzs[ndz++] = dz;
+    d_msg = bond_adjoint(c, g, H, d_min, partb, st);
+  }
+  float* d_inp = c.ar.f(g.nB, H);
+  RR_TRY(c, rr_relu_bwd_sum_f32(d_msg, S.msgs[0], 1.0f, dzs, ndz, d_inp, g.nB * static_cast<int64_t>(H), st));
+  rr_wgrad_args w = WA(g.nB, H, d_inp, H, G.wi, m.enc_wi.in, G.bi, accumulate);
+  w.x1 = g.f_bonds; w.ldx1 = g.ld_fb; w.k1 = m.bond_fdim;
+  wgrad(c, w);
+}
+
+void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_graph& g, const int32_t* bmap_t, int bmap_t_cols,
+                         const Packed& wh_t, const Packed& wo_t, float p, const EncSaved& S, const float* dH, float sign,
+                         const EncGrads& G, int accumulate) {
+  const int H = m.H, depth = m.depth;
+  const float ks = 1.0f / (1.0f - p);
+  hipStream_t st = c.s.main;
+  float* dz_o = c.ar.f(g.nA, H);
+  float* d_a = c.ar.f(g.nA, H);
+  float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
+  {
+    rr_linear_args a = LA(g.nA, H);
+    a.a1 = dH; a.lda1 = H; a.k1 = H; a.a_mask = S.h; a.ld_mask = H; a.mask_scale = sign * ks;
+    a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_t);
+    a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
+    a.c = d_a; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));
+  }
+  {
+    rr_wgrad_args w = WA(g.nA, H, dz_o, H, G.wo, m.enc_wo.in, G.bo, accumulate);
+    w.x1 = g.f_atoms; w.ldx1 = g.ld_fa; w.k1 = m.atom_fdim; w.x2 = S.a_last; w.ldx2 = H; w.k2 = H;
+    wgrad(c, w);
+  }
+  float* d_msg = c.ar.f(g.nB, H);
+  gather_sum(c, d_a, g.nA, H, g.b2t, g.nB, 1, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nA), r4(H));
+  float* d_inp_full = nullptr;
+  bool have_full = false;            // (flags, not pointer tests: a layout pass hands out null pointers)
+  int wh_started = accumulate;
+  for (int it = depth - 2; it >= 1; --it) {                                             // per-copy W_h layers
+    float* dz = c.ar.f(g.nB, H);
+    float* d_min = c.ar.f(g.nB, H);
+    float* partb = c.ar.f(rr_linear_colsum_rows(g.nB), r4(H));
+    rr_linear_args a = LA(g.nB, H);
+    a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.ld_mask = H; a.mask_scale = ks;
+    a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
+    a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
+    a.c = d_min; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));
+    rr_wgrad_args w = WA(g.nB, H, dz, H, G.wh, H, G.bh, wh_started);
+    w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x1_idx = g.b2a; w.x1_sub = S.msgs[it]; w.ldx1_sub = H; w.x1_sub_idx = g.b2revb;
+    wgrad(c, w);
+    wh_started = 1;
+    if (!have_full) {
+      d_inp_full = dz;
+      have_full = true;
+    } else {
+      float* sum = c.ar.f(g.nB, H);                                                     // fresh buffer (side-stream readers)
+      RR_TRY(c, rr_axpby_f32(1.0f, d_inp_full, 1.0f, dz, sum, g.nB * static_cast<int64_t>(H), st));
+      d_inp_full = sum;
+    }
+    d_msg = bond_adjoint(c, g, H, d_min, partb, st);
+  }
+  // ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
+  float* dz1_full = c.ar.f(g.nB, H);
+  RR_TRY(c, rr_relu_bwd_f32(d_msg, S.msgs[1], ks, dz1_full, nullptr, g.nB * static_cast<int64_t>(H), st));
+  float* dz1_u = c.ar.f(gu.nB, H);
+  gather_sum(c, dz1_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, dz1_u, H, st);      // sum over the copies
+  float* d_inp_u = c.ar.f(gu.nB, H);
+  if (have_full) {
+    gather_sum(c, d_inp_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, d_inp_u, H, st);
+    RR_TRY(c, rr_axpby_f32(1.0f, d_inp_u, 1.0f, dz1_u, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
+  } else {
+    RR_TRY(c, rr_axpby_f32(1.0f, dz1_u, 0.0f, nullptr, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
+  }
+  {
+    rr_wgrad_args w = WA(gu.nB, H, dz1_u, H, G.wh, H, G.bh, wh_started);
+    w.x1 = S.a0_u; w.ldx1 = H; w.k1 = H; w.x1_idx = gu.b2a; w.x1_sub = S.msg0_u; w.ldx1_sub = H; w.x1_sub_idx = gu.b2revb;
+    wgrad(c, w);
+  }
+  float* d_min_u = c.ar.f(gu.nB, H);
+  float* part_u = c.ar.f(rr_linear_colsum_rows(gu.nB), r4(H));
+  {
+    rr_linear_args a = LA(gu.nB, H);
+    a.a1 = dz1_u; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
+    a.colsum_w = gu.npad_b; a.colsum_partial = part_u; a.ld_partial = r4(H);
+    a.c = d_min_u; a.ldc = H;
+    RR_TRY(c, rr_linear_f32(&a, st));
+  }
+  float* d_msg0_u = bond_adjoint(c, gu, H, d_min_u, part_u, st);
+  RR_TRY(c, rr_relu_bwd_f32(d_msg0_u, S.msg0_u, 1.0f, nullptr, d_inp_u, gu.nB * static_cast<int64_t>(H), st));   // msg0 = relu(inp)
+  rr_wgrad_args w = WA(gu.nB, H, d_inp_u, H, G.wi, m.enc_wi.in, G.bi, accumulate);
+  w.x1 = gu.f_bonds; w.ldx1 = gu.ld_fb; w.k1 = m.bond_fdim;
+  wgrad(c, w);
+}
+
+// adjoint of mpndiff_forward -> d_x [nA, H]
+float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, const DiffSaved& S, const float* x, const float* x_sub,
+                        const int32_t* x_sub_idx, const float* dvecs, int64_t ld_dvecs, int F, uint64_t out_seed,
+                        const rr_grads& G) {
+  const int H = m.H, depth = m.diff_depth, FB = m.bond_fdim;
+  const float ks = 1.0f / (1.0f - p);
+  hipStream_t st = c.s.main;
+  float* d_hid = c.ar.f(g.nA, H);
+  RR_TRY(c, rr_segment_mean_bwd_f32(dvecs, ld_dvecs, g.a_scope, g.atom2mol, g.nA, H, F, p, out_seed, d_hid, H, st));
+  float* d_x = nullptr;
+  float* d_inp = nullptr;
+  if (depth > 0) {
+    const Packed wo_x = pack(c, m.dif_wo, 1, H, 0, H, 0, st);
+    const Packed wo_a = pack(c, m.dif_wo, 1, H, H, H, 0, st);
+    float* dz_o = c.ar.f(g.nA, H);
+    d_x = c.ar.f(g.nA, H);
+    {
+      rr_linear_args a = LA(g.nA, H);
+      a.a1 = d_hid; a.lda1 = H; a.k1 = H; a.a_mask = S.hid; a.ld_mask = H; a.mask_scale = ks;
+      a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_x); a.c = d_x; a.ldc = H;
+      RR_TRY(c, rr_linear_f32(&a, st));
+    }
+    {
+      rr_wgrad_args w = WA(g.nA, H, dz_o, H, G.w[RR_G_DIF_WO], 2 * H, G.b[RR_G_DIF_WO], 0);
+      w.x1 = x; w.ldx1 = H; w.k1 = H; w.x1_sub = x_sub; w.ldx1_sub = H; w.x1_sub_idx = x_sub_idx;
+      w.x2 = S.a_last; w.ldx2 = H; w.k2 = H;
+      wgrad(c, w);
+    }
+    float* d_a = c.ar.f(g.nA, H);
+    float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
+    {
+      rr_linear_args a = LA(g.nA, H);
+      a.a1 = d_hid; a.lda1 = H; a.k1 = H; a.a_mask = S.hid; a.ld_mask = H; a.mask_scale = ks;
+      set_w(a, wo_a); a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
+      a.c = d_a; a.ldc = H;
+      RR_TRY(c, rr_linear_f32(&a, st));
+    }
+    float* d_msg = c.ar.f(g.nA, H);
+    gather_sum(c, d_a, g.nA, H, g.a2a_t, g.nA, g.K, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nA), r4(H));
+    const float* dzs[MAXD];
+    int ndz = 0;
+    Packed wh_t;
+    if (depth > 1) wh_t = pack(c, m.dif_wh, 1, H, 0, H, 0, st);
+    for (int it = depth - 2; it >= 0; --it) {
+      float* dz = c.ar.f(g.nA, H);
+      float* d_a2 = c.ar.f(g.nA, H);
+      float* part2 = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
+      rr_linear_args a = LA(g.nA, H);
+      a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.ld_mask = H; a.mask_scale = ks;
+      a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
+      a.colsum_w = g.npad; a.colsum_partial = part2; a.ld_partial = r4(H);
+      a.c = d_a2; a.ldc = H;
+      RR_TRY(c, rr_linear_f32(&a, st));
+      rr_wgrad_args w = WA(g.nA, H, dz, H, G.w[RR_G_DIF_WH], H + FB, G.b[RR_G_DIF_WH], it != depth - 2 ? 1 : 0);
+      w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x2 = g.fb_sum; w.ldx2 = g.ld_fbs; w.k2 = FB;
+      wgrad(c, w);
+      dzs[ndz++] = dz;
+      d_msg = c.ar.f(g.nA, H);
+      gather_sum(c, d_a2, g.nA, H, g.a2a_t, g.nA, g.K, H, d_msg, H, st, part2, rr_linear_colsum_rows(g.nA), r4(H));
+    }
+    d_inp = c.ar.f(g.nA, H);
+    RR_TRY(c, rr_relu_bwd_sum_f32(d_msg, S.msgs[0], 1.0f, dzs, ndz, d_inp, g.nA * static_cast<int64_t>(H), st));
+  } else {
+    d_inp = c.ar.f(g.nA, H);
+    RR_TRY(c, rr_relu_bwd_f32(d_hid, S.msgs[0], ks, d_inp, nullptr, g.nA * static_cast<int64_t>(H), st));   // hid = drop(relu(inp))
+  }
+  {
+    rr_wgrad_args w = WA(g.nA, H, d_inp, H, G.w[RR_G_DIF_WI], H, G.b[RR_G_DIF_WI], 0);
+    w.x1 = x; w.ldx1 = H; w.k1 = H; w.x1_sub = x_sub; w.ldx1_sub = H; w.x1_sub_idx = x_sub_idx;
+    wgrad(c, w);
+  }
+  const Packed wi_t = pack(c, m.dif_wi, 1, H, 0, H, 0, st);
+  rr_linear_args a = LA(g.nA, H);
+  a.a1 = d_inp; a.lda1 = H; a.k1 = H; set_w(a, wi_t);
+  if (depth == 0) {
+    d_x = c.ar.f(g.nA, H);
+  } else {
+    a.residual = d_x; a.ldr = H;
+  }
+  a.c = d_x; a.ldc = H;
+  RR_TRY(c, rr_linear_f32(&a, st));
+  return d_x;
+}
+
+// adjoint of ffn_forward -> d vecs [M, H] (the readout columns only)
+float* ffn_backward(Ctx& c, const rr_model& m, int64_t M, float p, const FfnSaved& S, const float* dout, const rr_grads& G,
+                    int64_t* ld_out) {
+  const float ks = 1.0f / (1.0f - p);
+  hipStream_t st = c.s.main;
+  const int nl = m.n_ffn;
+  const rr_linear_w& L = m.ffn[nl - 1];
+  const float* d = dout;
+  if (m.head != 0) {
+    float* draw = c.ar.f(M, L.out);
+    RR_TRY(c, rr_head_bwd_f32(dout, S.raw, M, L.out, m.head, draw, st));
+    d = draw;
+  }
+  {
+    rr_wgrad_args w = WA(M, L.out, d, L.out, G.w[RR_G_FFN0 + nl - 1], L.in, G.b[RR_G_FFN0 + nl - 1], 0);
+    w.x1 = S.hs[nl - 1]; w.ldx1 = S.ld_hs[nl - 1]; w.k1 = L.in;
+    wgrad(c, w);
+  }
+  const int dx_cols = nl > 1 ? m.H : L.in;               // first layer: only the readout columns carry a gradient
+  int ncur = (nl > 1) ? L.in : dx_cols;
+  float* dx = c.ar.f(M, r4(ncur));
+  int64_t ld_dx = r4(ncur);
+  {
+    const Packed wt = pack(c, L, 1, ncur, 0, L.out, 0, st);
+    rr_linear_args a = LA(M, ncur);
+    a.a1 = d; a.lda1 = L.out; a.k1 = L.out; set_w(a, wt); a.c = dx; a.ldc = ld_dx;
+    RR_TRY(c, rr_linear_f32(&a, st));
+  }
+  for (int li = nl - 2; li >= 0; --li) {
+    const rr_linear_w& Lh = m.ffn[li];
+    const float* y = S.hs[li + 1];                       // drop(relu(.)) output of this layer
+    {
+      rr_wgrad_args w = WA(M, Lh.out, dx, ld_dx, G.w[RR_G_FFN0 + li], Lh.in, G.b[RR_G_FFN0 + li], 0);
+      w.mask = y; w.ld_mask = S.ld_hs[li + 1]; w.mask_scale = ks;
+      w.x1 = S.hs[li]; w.ldx1 = S.ld_hs[li]; w.k1 = Lh.in;
+      wgrad(c, w);
+    }
+    const int nin = li > 0 ? Lh.in : dx_cols;
+    float* dn = c.ar.f(M, r4(nin));
+    const Packed wt = pack(c, Lh, 1, nin, 0, Lh.out, 0, st);
+    rr_linear_args a = LA(M, nin);
+    a.a1 = dx; a.lda1 = ld_dx; a.k1 = Lh.out; a.a_mask = y; a.ld_mask = S.ld_hs[li + 1]; a.mask_scale = ks;
+    set_w(a, wt); a.c = dn; a.ldc = r4(nin);
+    RR_TRY(c, rr_linear_f32(&a, st));
+    dx = dn;
+    ld_dx = r4(nin);
+  }
+  *ld_out = ld_dx;
+  return dx;
+}
+
+void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const float* dout, const rr_grads& G) {
+  const int H = m.H;
+  const float p = s.drop_p;
+  hipStream_t main = c.s.main;
+  int64_t ld_dvecs = 0;
+  float* dvecs = ffn_backward(c, m, s.p.M, p, P.f, dout, G, &ld_dvecs);
+  const int32_t* xsi = s.mode == RR_STEP_DEDUP ? s.amap : nullptr;
+  float* d_diff = mpndiff_backward(c, m, s.p, p, P.d, P.p.h, P.r.h, xsi, dvecs, ld_dvecs, s.F, site_seed(s.seed, 4), G);
+  // de-duplicated reactants: d r_h[u] = -(sum over the copies of atom u of d_diff) (fixed-order segment sum)
+  const float* d_r = d_diff;
+  if (s.mode == RR_STEP_DEDUP) {
+    float* t = c.ar.f(s.r.nA, H);
+    gather_sum(c, d_diff, s.p.nA, H, s.amap_t, s.r.nA, s.amap_t_cols, H, t, H, main);
+    d_r = t;
+  }
+  Packed wh_t;
+  if (m.depth > 1) wh_t = pack(c, m.enc_wh, 1, H, 0, H, 0, main);
+  const Packed wo_t = pack(c, m.enc_wo, 1, H, m.atom_fdim, H, 0, main);
+  EncGrads E;
+  E.wi = G.w[RR_G_ENC_WI]; E.bi = G.b[RR_G_ENC_WI]; E.wh = G.w[RR_G_ENC_WH]; E.bh = G.b[RR_G_ENC_WH];
+  E.wo = G.w[RR_G_ENC_WO]; E.bo = G.b[RR_G_ENC_WO];
+  // the two encoder passes share weights: the product pass writes the gradient buffers, the reactant pass accumulates
+  mpn_backward(c, m, s.p, P.pk, wh_t, wo_t, p, P.p, d_diff, 1.0f, E, 0);
+  if (s.mode == RR_STEP_PREFIX) mpn_backward_shared(c, m, s.u, s.r, s.bmap_t, s.bmap_t_cols, wh_t, wo_t, p, P.r, d_r, -1.0f, E, 1);
+  else mpn_backward(c, m, s.r, P.pk, wh_t, wo_t, p, P.r, d_r, -1.0f, E, 1);
+  if (c.launch && c.use_side) c.fail(stream_wait(main, c.s.side));     // weight gradients are complete from here on
+}
+
+int check_graph(const rr_graph& g, int need_fb_sum, int need_f_bonds) {
+  RR_CHECK_ARG(g.nA >= 1 && g.nB >= 1 && g.M >= 0 && g.K >= 1 && g.Kb >= 1);
+  RR_CHECK_ARG(!need_f_bonds || g.f_bonds);
+  RR_CHECK_ARG(g.f_atoms && g.a2b && g.b2a && g.b2revb && g.a2a && g.a_scope && g.b2t && g.a2a_t && g.atom2mol &&
+               g.b2b_t && g.npad && g.npad_b);
+  RR_CHECK_ARG(!need_fb_sum || g.fb_sum);
+  return RR_OK;
+}
+
+int check(const rr_model* m, const rr_step* s) {
+  RR_CHECK_ARG(m && s);
+  RR_CHECK_ARG(m->H >= 4 && m->H % 4 == 0 && m->depth >= 1 && m->depth <= MAXD && m->diff_depth >= 0 && m->diff_depth <= MAXD);
+  RR_CHECK_ARG(m->n_ffn >= 1 && m->n_ffn <= RR_MAX_FFN && m->atom_fdim == ATOM_FDIM && m->bond_fdim >= 1);
+  RR_CHECK_ARG(m->enc_wi.w && m->enc_wo.w && m->dif_wi.w && (m->depth == 1 || m->enc_wh.w) && (m->diff_depth <= 1 || m->dif_wh.w) &&
+               (m->diff_depth == 0 || m->dif_wo.w));
+  RR_CHECK_ARG(s->mode == RR_STEP_PLAIN || s->mode == RR_STEP_DEDUP || s->mode == RR_STEP_PREFIX);
+  RR_CHECK_ARG(s->drop_p >= 0.f && s->drop_p < 1.f && s->F >= 0 && (s->F == 0 || s->feat) && s->out);
+  int st = check_graph(s->p, m->diff_depth > 1, 1);
+  if (st != RR_OK) return st;
+  st = check_graph(s->r, 0, s->mode != RR_STEP_PREFIX);    // shared prefix: W_i reads the distinct reactants' f_bonds only
+  if (st != RR_OK) return st;
+  if (s->mode == RR_STEP_DEDUP) RR_CHECK_ARG(s->amap && s->amap_t && s->amap_t_cols >= 1 && s->drop_p == 0.f);
+  else RR_CHECK_ARG(s->r.nA == s->p.nA);
+  if (s->mode == RR_STEP_PREFIX) {
+    RR_CHECK_ARG(m->depth >= 2 && s->bmap && s->bmap_t && s->bmap_t_cols >= 1);
+    st = check_graph(s->u, 0, 1);
+    if (st != RR_OK) return st;
+  }
+  RR_CHECK_ARG(m->ffn[0].in == m->H + s->F);
+  return RR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rr_abi_plan_struct_sizes(size_t* graph, size_t* model, size_t* step, size_t* grads) {
+  if (graph) *graph = sizeof(rr_graph);
+  if (model) *model = sizeof(rr_model);
+  if (step) *step = sizeof(rr_step);
+  if (grads) *grads = sizeof(rr_grads);
+}
+
+size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
+  if (check(model, step) != RR_OK) return 0;
+  Ctx c;
+  c.launch = false; c.status = RR_OK; c.ar.base = nullptr; c.ar.off = 0; c.ar.cap = 0; c.ar.overflow = false;
+  c.use_side = c.use_aux = false;
+  Plan P;
+  memset(&P, 0, sizeof(P));
+  forward_all(c, *model, *step, P);
+  rr_grads G;
+  memset(&G, 0, sizeof(G));
+  backward_all(c, *model, *step, P, nullptr, G);
+  return c.ar.off + 256;
+}
+
+int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, rr_stream_t stream) {
+  int st = check(model, step);
+  if (st != RR_OK) return st;
+  RR_CHECK_ARG(step->workspace && rr_aligned16(step->workspace));
+  Ctx c;
+  c.launch = true; c.status = RR_OK;
+  c.ar.base = static_cast<char*>(step->workspace); c.ar.off = 0; c.ar.cap = step->workspace_bytes; c.ar.overflow = false;
+  c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
+  c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
+  st = get_streams(static_cast<hipStream_t>(stream), &c.s);
+  if (st != RR_OK) return st;
+  // the layout must fit BEFORE anything is launched (a dry pass costs microseconds)
+  {
+    Ctx d = c;
+    d.launch = false; d.ar.base = nullptr;
+    Plan Q;
+    memset(&Q, 0, sizeof(Q));
+    forward_all(d, *model, *step, Q);
+    if (d.ar.off > step->workspace_bytes) return RR_ERR_WORKSPACE;
+  }
+  Plan P;
+  memset(&P, 0, sizeof(P));
+  forward_all(c, *model, *step, P);
+  return c.ar.overflow ? RR_ERR_WORKSPACE : c.status;
+}
+
+int rr_reaction_backward(const rr_model* model, const rr_step* step, const float* dout, const rr_grads* grads, int flags,
+                         rr_stream_t stream) {
+  int st = check(model, step);
+  if (st != RR_OK) return st;
+  RR_CHECK_ARG(step->workspace && dout && grads);
+  for (int i = 0; i < RR_G_FFN0 + model->n_ffn; ++i) {
+    const bool needed = !((i == RR_G_ENC_WH && model->depth <= 1) || (i == RR_G_DIF_WH && model->diff_depth <= 1) ||
+                          (i == RR_G_DIF_WO && model->diff_depth == 0));
+    RR_CHECK_ARG(!needed || grads->w[i]);
+  }
+  Ctx c;
+  c.launch = false; c.status = RR_OK;
+  c.ar.base = static_cast<char*>(step->workspace); c.ar.off = 0; c.ar.cap = step->workspace_bytes; c.ar.overflow = false;
+  c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
+  c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
+  st = get_streams(static_cast<hipStream_t>(stream), &c.s);
+  if (st != RR_OK) return st;
+  Plan P;
+  memset(&P, 0, sizeof(P));
+  forward_all(c, *model, *step, P);                      // layout pass: re-derives the address of every saved activation
+  {
+    Ctx d = c;                                           // ... and the backward's temporaries must fit as well
+    d.ar.base = nullptr;
+    Plan Q = P;
+    backward_all(d, *model, *step, Q, dout, *grads);
+    if (d.ar.off > step->workspace_bytes) return RR_ERR_WORKSPACE;
+  }
+  c.launch = true;
+  backward_all(c, *model, *step, P, dout, *grads);
+  return c.ar.overflow ? RR_ERR_WORKSPACE : c.status;
+}
+
+}  // extern "C"

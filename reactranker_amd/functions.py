@@ -431,15 +431,21 @@ def _pad_row_fix(d_src, d_out, g, H):
     weighted_colsum(d_out, g.npad, H, d_src[0], accumulate=True)
 
 
-def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p: float, saved, dH, sign: float):
+def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p: float, saved, dH, sign: float, into=None):
     """Adjoint of mpn_forward.  `dH` is d loss / d atom_hiddens times `sign` (the reactant encoder
-    sees -d_diff, models/base_model.py:168).  Returns grads (gWi, gbi, gWh, gbh, gWo, gbo)."""
+    sees -d_diff, models/base_model.py:168).  Returns grads (gWi, gbi, gWh, gbh, gWo, gbo).
+    into: gradient buffers that already hold the OTHER encoder pass (the two passes share weights): this pass
+    accumulates into them instead of returning fresh buffers that would have to be added afterwards."""
     msgs, amsgs, a_last, h = saved
     nA, nB = g.nA, g.nB
     ks = 1.0 / (1.0 - p)
-    gWi, gbi = Wi.grads()
-    gWo, gbo = Wo.grads()
-    gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
+    acc0 = into is not None
+    if acc0:
+        gWi, gbi, gWh, gbh, gWo, gbo = into
+    else:
+        gWi, gbi = Wi.grads()
+        gWo, gbo = Wo.grads()
+        gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
     # atom_hiddens = drop(relu([f_atoms | a_last] W_o^T + b_o))
     fused = (H % 4 == 0)                                             # ReLU backward fused into the GEMM operand loads
     # Fused form: the input-gradient GEMM applies the ReLU/dropout mask in its operand loader and writes the masked
@@ -450,11 +456,12 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
         # ... and the padding row's adjoint sum_a npad[a] * d_a[a] as per-row-block partial sums (colsum_w)
         d_a, part = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h,
                            mask_scale=sign * ks, dz_out=dz_o, colsum_w=g.npad)
-        wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
+        wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, accumulate=acc0, side=True)
         # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)]
         d_msg = gather_sum(d_a, g.b2t, H, row0_partial=part)
     else:
-        wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
+        wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H,
+              accumulate=acc0, side=True)
         d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
         d_msg = gather_sum(d_a, g.b2t, H)
         _pad_row_fix(d_msg, d_a, g, H)
@@ -468,7 +475,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
             d_min, part = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
                                  dz_out=dz, colsum_w=g.npad_b)
             wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
-                  accumulate=(it != depth - 2), side=True)
+                  accumulate=(acc0 or it != depth - 2), side=True)
             dzs.append(dz)
             d_msg = bond_message_adjoint(d_min, g, H, part)          # fresh buffer: the side stream may still read the old one
             continue
@@ -480,7 +487,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
                 d_inp = torch.zeros_like(d_msg)
             dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=torch.empty_like(d_msg), acc=d_inp)
             wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it],
-                  x1_sub_idx=g.b2revb, accumulate=(it != depth - 2), side=True)
+                  x1_sub_idx=g.b2revb, accumulate=(acc0 or it != depth - 2), side=True)
             d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
         d_msg = bond_message_adjoint(d_min, g, H)
     # msgs[0] = relu(inp);  d inp = sum_it dZ_it + relu'(inp) * d msgs[0]   (inp is the residual of every iteration, :94)
@@ -490,7 +497,7 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
         d_inp = relu_bwd(d_msg, msgs[0], 1.0)
     else:
         relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
-    wgrad(nB, H, d_inp, gWi, dbias=gbi, x1=g.f_bonds, k1=FBOND, side=True)
+    wgrad(nB, H, d_inp, gWi, dbias=gbi, x1=g.f_bonds, k1=FBOND, accumulate=acc0, side=True)
     return gWi, gbi, gWh, gbh, gWo, gbo
 
 
@@ -523,7 +530,8 @@ def mpn_forward_shared(gu, g, bmap, H: int, depth: int, Wi: LinW, Wh: LinW, Wo: 
     return h, (msgs, amsgs, a_last, h, (msg0_u, a0_u))
 
 
-def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, Wo: LinW, p: float, saved, dH, sign: float):
+def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, Wo: LinW, p: float, saved, dH, sign: float,
+                        into=None):
     """Adjoint of mpn_forward_shared.  The per-copy layers run as in mpn_backward; the gradients that reach
     the shared prefix are summed over the copies (fixed-order segment sums over `bmap_t`) and the prefix is
     back-propagated once on the distinct molecules — every op there is linear in the gradient, so the sum
@@ -531,16 +539,20 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
     msgs, amsgs, a_last, h, (msg0_u, a0_u) = saved
     nA, nB, nBu = g.nA, g.nB, gu.nB
     ks = 1.0 / (1.0 - p)
-    gWi, gbi = Wi.grads()
-    gWo, gbo = Wo.grads()
-    gWh, gbh = Wh.grads()
+    acc0 = into is not None                                          # see mpn_backward
+    if acc0:
+        gWi, gbi, gWh, gbh, gWo, gbo = into
+    else:
+        gWi, gbi = Wi.grads()
+        gWo, gbo = Wo.grads()
+        gWh, gbh = Wh.grads()
     dz_o = torch.empty_like(dH)                                      # masked gradient as a side output (see mpn_backward)
     d_a, part = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks,
                        dz_out=dz_o, colsum_w=g.npad)
-    wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, side=True)
+    wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, accumulate=acc0, side=True)
     d_msg = gather_sum(d_a, g.b2t, H, row0_partial=part)
     d_inp_full = None
-    wh_started = False
+    wh_started = acc0
     for it in reversed(range(1, depth - 1)):                         # per-copy W_h layers
         dz = torch.empty_like(d_msg)
         d_min, part = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
@@ -563,7 +575,7 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
     d_min_u, part_u = linear(nBu, H, Wh.pk_t(0, H), w_packed=True, a1=dz1_u, k1=H, colsum_w=gu.npad_b)
     d_msg0_u = bond_message_adjoint(d_min_u, gu, H, part_u)
     relu_bwd(d_msg0_u, msg0_u, 1.0, acc=d_inp_u, want_dz=False)       # msg0 = relu(inp)
-    wgrad(nBu, H, d_inp_u, gWi, dbias=gbi, x1=gu.f_bonds, k1=FBOND, side=True)
+    wgrad(nBu, H, d_inp_u, gWi, dbias=gbi, x1=gu.f_bonds, k1=FBOND, accumulate=acc0, side=True)
     return gWi, gbi, gWh, gbh, gWo, gbo
 
 
@@ -770,12 +782,112 @@ class SegmentMeanFn(torch.autograd.Function):
         return segment_mean_bwd(_rowmajor(dout, "grad"), ctx.g, ctx.H, 0, 0.0, 0), None, None
 
 
+class StepPlan:
+    """The whole forward / backward of the model as ONE C-ABI call each (rr_reaction_forward / rr_reaction_backward,
+    csrc/plan.hip): the launch sequence below (mpn_forward ... ffn_backward) issued by native code instead of ~140
+    ctypes calls, cutting the host's enqueue time per training step from ~4 ms to well under 1 ms.  Same kernels, same
+    order, same dropout streams: results are bit-identical to the per-op path (tests/test_gpu_plan.py).  Used when the
+    shape qualifies (H % 4 == 0) and no per-launch profiling is requested."""
+    enabled = True
+    _ws_bytes = {}
+
+    @staticmethod
+    def eligible(st, params) -> bool:
+        if not StepPlan.enabled or Profiler.enabled or st["H"] % 4 != 0:
+            return False
+        if st["depth"] > 16 or st["diff_depth"] > 16 or (len(params) - 12) // 2 > _lib.RR_MAX_FFN:
+            return False
+        return all(q is None or (q.dtype == torch.float32 and q.is_cuda) for q in params)
+
+    @staticmethod
+    def graph_struct(g, need_fb_sum: bool, need_f_bonds: bool = True) -> "_lib.Graph":
+        G = _lib.Graph()
+        G.nA, G.nB, G.M, G.K, G.Kb = g.nA, g.nB, g.M, g.K, g.b2b_t.shape[1]
+        G.f_atoms, G.ld_fa = ptr(g.f_atoms), g.f_atoms.stride(0)
+        if need_f_bonds:                                 # (a streamed batch rebuilds f_bonds lazily: only ask when it is read)
+            fb = g.f_bonds
+            G.f_bonds, G.ld_fb = ptr(fb), fb.stride(0)
+        for k in ("a2b", "b2a", "b2revb", "a2a", "a_scope", "b2t", "a2a_t", "atom2mol", "b2b_t", "npad", "npad_b"):
+            setattr(G, k, ptr(getattr(g, k)))
+        if need_fb_sum:
+            fs = g.fb_sum()
+            G.fb_sum, G.ld_fbs = ptr(fs), fs.stride(0)
+        return G
+
+    @staticmethod
+    def build(st, params, out):
+        """(Model, Step, keep-alive list) for this call."""
+        keep = []
+
+        def lw(w, b):
+            L = _lib.LinearW()
+            if w is not None:
+                w = _rowmajor(w.detach(), "weight")
+                keep.append(w)
+                L.w, L.out, L.in_, L.ldw = ptr(w), w.shape[0], w.shape[1], w.stride(0)
+                if b is not None:
+                    b = _rowmajor(b.detach(), "bias")
+                    keep.append(b)
+                    L.b = ptr(b)
+            return L
+        M = _lib.Model()
+        M.H, M.depth, M.diff_depth, M.head = st["H"], st["depth"], st["diff_depth"], st["head"]
+        M.atom_fdim, M.bond_fdim = ATOM_FDIM, FBOND
+        M.enc_wi, M.enc_wh, M.enc_wo = lw(params[0], params[1]), lw(params[2], params[3]), lw(params[4], params[5])
+        M.dif_wi, M.dif_wh, M.dif_wo = lw(params[6], params[7]), lw(params[8], params[9]), lw(params[10], params[11])
+        nf = (len(params) - 12) // 2
+        M.n_ffn = nf
+        for i in range(nf):
+            M.ffn[i] = lw(params[12 + 2 * i], params[13 + 2 * i])
+        S = _lib.Step()
+        pg, rg = st["p_graph"], st["r"]
+        dd, px = st.get("dedup"), st.get("prefix")
+        S.p = StepPlan.graph_struct(pg, st["diff_depth"] > 1)
+        S.r = StepPlan.graph_struct(rg, False, need_f_bonds=(px is None))   # shared prefix: W_i runs on the distinct reactants
+        S.mode = _lib.RR_STEP_PLAIN
+        if dd is not None:
+            S.mode = _lib.RR_STEP_DEDUP
+            S.amap, S.amap_t, S.amap_t_cols = ptr(dd[1]), ptr(dd[2]), dd[2].shape[1]
+            keep += [dd[1], dd[2]]
+        elif px is not None:
+            S.mode = _lib.RR_STEP_PREFIX
+            S.u = StepPlan.graph_struct(px[0], False)
+            S.bmap, S.bmap_t, S.bmap_t_cols = ptr(px[1]), ptr(px[2]), px[2].shape[1]
+            keep += [px[1], px[2]]
+        feat = st["feat"]
+        S.feat, S.F = ptr(feat), st["F"]
+        S.drop_p, S.seed = float(st["p"]), int(st["seed"]) & 0xFFFFFFFFFFFFFFFF
+        S.out = ptr(out)
+        return M, S, keep
+
+    @staticmethod
+    def flags() -> int:
+        return (0 if SideStream.enabled else _lib.RR_PLAN_NO_SIDE_STREAM) | (0 if AuxStream.enabled else _lib.RR_PLAN_NO_AUX_STREAM)
+
+
 class ReactionModelFn(torch.autograd.Function):
     """ReactionModel.forward (models/base_model.py:150-171) with an explicit backward."""
 
     @staticmethod
     def forward(ctx, st, *params):
         # params order: enc(Wi w,b, Wh w,b, Wo w,b), diff(Wi w,b, Wh w,b, Wo w,b), ffn (w,b)*
+        ctx.plan = None
+        if StepPlan.eligible(st, params):
+            pg = st["p_graph"]
+            n_out = params[-2].shape[0]
+            out = torch.empty(pg.M, n_out, dtype=torch.float32, device=pg.device)
+            M, S, keep = StepPlan.build(st, params, out)
+            nbytes = int(lib().rr_reaction_workspace_bytes(C.byref(M), C.byref(S)))
+            if nbytes == 0:
+                raise RuntimeError("rr_reaction_workspace_bytes rejected the step (inconsistent model / batch shapes)")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=pg.device)
+            S.workspace, S.workspace_bytes = C.c_void_p(ws.data_ptr()), nbytes
+            check(lib().rr_reaction_forward(C.byref(M), C.byref(S), StepPlan.flags(), stream()), "rr_reaction_forward")
+            ctx.plan = (M, S, keep, ws, out)
+            ctx.st = st
+            ctx.param_shapes = [None if q is None else q for q in params]
+            ctx.present = [q is not None for q in params]
+            return out.reshape(-1) if st["squeeze"] else out
         enc = [LinW(params[0], params[1]), LinW(params[2], params[3]) if params[2] is not None else None,
                LinW(params[4], params[5])]
         dif = [LinW(params[6], params[7]), LinW(params[8], params[9]) if params[8] is not None else None,
@@ -822,6 +934,25 @@ class ReactionModelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         st = ctx.st
+        if ctx.plan is not None:
+            if ctx.plan == "done":
+                raise RuntimeError("ReactionModelFn: backward ran twice; the saved activations are released after the "
+                                   "first backward (retain_graph=True is not supported by the explicit backward)")
+            M, S, keep, ws, out = ctx.plan
+            dout = _rowmajor(dout.reshape(out.shape), "grad_output")
+            G = _lib.Grads()
+            grads = []
+            order = [0, 2, 4, 6, 8, 10] + list(range(12, len(ctx.param_shapes), 2))     # weights; bias = index + 1
+            for gi, wi in enumerate(order):
+                w, b = ctx.param_shapes[wi], ctx.param_shapes[wi + 1]
+                gw = None if w is None else torch.empty_like(w, memory_format=torch.contiguous_format)
+                gb = None if b is None else torch.empty_like(b)
+                G.w[gi], G.b[gi] = ptr(gw), ptr(gb)
+                grads += [gw, gb]
+            check(lib().rr_reaction_backward(C.byref(M), C.byref(S), ptr(dout), C.byref(G), StepPlan.flags(), stream()),
+                  "rr_reaction_backward")
+            ctx.plan = "done"
+            return (None, *grads)
         enc, dif, ffn = ctx.mods
         if ctx.saved is None:
             raise RuntimeError("ReactionModelFn: backward ran twice; the saved activations are released after the first "
@@ -854,17 +985,18 @@ class ReactionModelFn(torch.autograd.Function):
             for t in gr:
                 if t is not None:
                     t.record_stream(main)
+            SideStream.join(dout.device)
+            genc = [None if a is None else axpby(1.0, a, 1.0, b, out=a) for a, b in zip(gp, gr)]
         else:
+            # the two encoder passes share weights: the reactant pass accumulates into the product pass's buffers
             gp = mpn_backward(pg, H, st["depth"], enc[0], enc[1], enc[2], p, p_saved, d_diff, 1.0)
             px = st.get("prefix")
             if px is not None:
-                gr = mpn_backward_shared(px[0], rg, px[2], H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0)
+                mpn_backward_shared(px[0], rg, px[2], H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0, into=gp)
             else:
-                gr = mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0)
+                mpn_backward(rg, H, st["depth"], enc[0], enc[1], enc[2], p, r_saved, d_r, -1.0, into=gp)
+            genc = list(gp)
         SideStream.join(dout.device)                                # weight gradients are complete from here on
-        genc = []
-        for a, b in zip(gp, gr):                                    # the two encoder passes share weights
-            genc.append(None if a is None else axpby(1.0, a, 1.0, b, out=a))
         grads = list(genc) + [gWi, gbi, gWh, gbh, gWo, gbo]
         for gw, gb in fg:
             grads += [gw, gb]
