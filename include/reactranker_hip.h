@@ -174,6 +174,14 @@ int64_t rr_packed_weight_ld(int k1, int k2);
 int rr_pack_weight_f32(const float* src, int64_t ld_src, int transpose, int rows, int c0, int k1, int k2,
                        float* dst, rr_stream_t stream);
 
+/* rr_pack_weight_f32 for up to RR_MAX_PACK weights in one launch (`descs` is a HOST array). */
+#define RR_MAX_PACK 16
+typedef struct rr_pack_desc {
+  const float* src;  int64_t ld_src;  int transpose, rows, c0, k1, k2;
+  float* dst;
+} rr_pack_desc;
+int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream);
+
 /* dW[n, k] (+)= sum_m dZ[m,n] * X[m,k],   dbias[n] (+)= sum_m dZ[m,n]
  * dZ[m,n] = dy[m,n] * (mask ? (mask[m,n] > 0) * mask_scale : 1);  X = [X1 | X2] described
  * exactly like A above.  Weight gradients of every nn.Linear on the path; the sum over the

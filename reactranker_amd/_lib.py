@@ -117,6 +117,7 @@ _SIGS = {
     "rr_gather_sum_padrow_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, c_f32p, i64, c_stream]),
     "rr_packed_weight_ld": (i64, [i32, i32]),
     "rr_pack_weight_f32": (i32, [c_f32p, i64, i32, i32, i32, i32, i32, c_f32p, c_stream]),
+    "rr_pack_weights_f32": (i32, [C.c_void_p, i32, c_stream]),
     "rr_linear_wgrad_workspace_bytes": (C.c_size_t, [i64, i32, i32]),
     "rr_linear_wgrad_f32": (i32, [C.POINTER(WgradArgs), c_stream]),
     "rr_dropout_keep_host": (i32, [u64, u64, f32]),

@@ -593,6 +593,29 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
   }
 }
 
+// the same for up to RR_MAX_PACK weights in ONE launch (blockIdx.y = weight): a training step re-packs ~10 weights
+// for its forward and ~10 transposes for its backward, each a 2-5 us kernel with a launch boundary around it
+constexpr int RR_MAX_PACK_DEV = RR_MAX_PACK;
+struct PackMany {
+  rr_pack_desc d[RR_MAX_PACK_DEV];
+};
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackMany P) {
+  const rr_pack_desc& q = P.d[blockIdx.y];
+  const int k1p = r16(q.k1), ldd = r16(q.k1) + r16(q.k2);
+  const int64_t total = static_cast<int64_t>(q.rows) * ldd;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int r = static_cast<int>(e / ldd), c = static_cast<int>(e - static_cast<int64_t>(r) * ldd);
+    int lc = -1;
+    if (c < q.k1) lc = c;
+    else if (c >= k1p && c - k1p < q.k2) lc = q.k1 + (c - k1p);
+    float v = 0.f;
+    if (lc >= 0)
+      v = q.transpose ? q.src[static_cast<int64_t>(lc) * q.ld_src + q.c0 + r] : q.src[static_cast<int64_t>(r) * q.ld_src + q.c0 + lc];
+    q.dst[e] = v;
+  }
+}
+
 // ======================================================================== weight gradient
 constexpr int WT = 5;               // 5x5 MFMA tiles (80 x 80) per wave
 constexpr int WBN = 160;            // workgroup output tile: 160 (n) x 160 (k), 2x2 waves
@@ -1193,6 +1216,24 @@ int rr_pack_weight_f32(const float* src, int64_t ld_src, int transpose, int rows
   const int64_t total = static_cast<int64_t>(rows) * (r16(k1) + r16(k2));
   pack_weight_kernel<<<rr_grid_for(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(src, ld_src, transpose, rows,
                                                                                            c0, k1, k2, dst);
+  return rr_launch_status();
+}
+
+int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
+  RR_CHECK_ARG(descs && n >= 0 && n <= RR_MAX_PACK);
+  if (n == 0) return RR_OK;
+  PackMany P;
+  int64_t biggest = 0;
+  for (int i = 0; i < n; ++i) {
+    const rr_pack_desc& q = descs[i];
+    RR_CHECK_ARG(q.src && q.dst && q.rows >= 1 && q.c0 >= 0 && q.k1 >= 0 && q.k2 >= 0 && q.k1 + q.k2 >= 1 && q.ld_src >= 1);
+    P.d[i] = q;
+    const int64_t total = static_cast<int64_t>(q.rows) * (r16(q.k1) + r16(q.k2));
+    if (total > biggest) biggest = total;
+  }
+  for (int i = n; i < RR_MAX_PACK; ++i) P.d[i] = descs[0];
+  dim3 grid(static_cast<unsigned>(rr_grid_for(biggest, 256, 64)), static_cast<unsigned>(n));
+  pack_weights_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
   return rr_launch_status();
 }
 

@@ -73,12 +73,17 @@ int stream_wait(hipStream_t waiter, hipStream_t signaller) {
   return st;
 }
 
+// packed weight [rows, r16(k1)+r16(k2)] of W[:, c0 : c0+k1+k2] (transpose = 0) or of its transpose
+struct Packed { const float* w; int64_t ld; };
+
 struct Ctx {
   bool launch;                        // false: layout pass only (no kernel is enqueued)
   int status;
   Arena ar;
   Streams s;
   bool use_side, use_aux;
+  rr_pack_desc pq[RR_MAX_PACK];       // weight packs waiting for flush_packs()
+  int npq;
   void fail(int st) { if (status == RR_OK && st != RR_OK) status = st; }
 };
 
@@ -91,6 +96,22 @@ struct Ctx {
     }                                                                                             \
   } while (0)
 
+void flush_packs(Ctx& c, hipStream_t st) {
+  if (c.npq > 0) RR_TRY(c, rr_pack_weights_f32(c.pq, c.npq, st));
+  c.npq = 0;
+}
+
+Packed pack(Ctx& c, const rr_linear_w& L, int transpose, int rows, int c0, int k1, int k2, hipStream_t st) {
+  Packed p;
+  p.ld = rr_packed_weight_ld(k1, k2);
+  float* dst = c.ar.f(rows, p.ld);
+  p.w = dst;
+  if (c.npq == RR_MAX_PACK) flush_packs(c, st);
+  rr_pack_desc& q = c.pq[c.npq++];
+  q.src = L.w; q.ld_src = L.ldw; q.transpose = transpose; q.rows = rows; q.c0 = c0; q.k1 = k1; q.k2 = k2; q.dst = dst;
+  return p;
+}
+
 rr_linear_args LA(int64_t M, int N) {
   rr_linear_args a;
   memset(&a, 0, sizeof(a));
@@ -101,16 +122,7 @@ rr_linear_args LA(int64_t M, int N) {
   return a;
 }
 
-// packed weight [rows, r16(k1)+r16(k2)] of W[:, c0 : c0+k1+k2] (transpose = 0) or of its transpose
-struct Packed { const float* w; int64_t ld; };
-Packed pack(Ctx& c, const rr_linear_w& L, int transpose, int rows, int c0, int k1, int k2, hipStream_t st) {
-  Packed p;
-  p.ld = rr_packed_weight_ld(k1, k2);
-  float* dst = c.ar.f(rows, p.ld);
-  p.w = dst;
-  RR_TRY(c, rr_pack_weight_f32(L.w, L.ldw, transpose, rows, c0, k1, k2, dst, st));
-  return p;
-}
+// Packs are queued and issued together (rr_pack_weights_f32: one launch for up to 16 weights) by flush_packs().
 
 void set_w(rr_linear_args& a, const Packed& p) { a.w = p.w; a.ldw = p.ld; a.w_packed = 1; }
 
@@ -336,6 +348,11 @@ void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
   P.pk.enc_wi = pack(c, m.enc_wi, 0, H, 0, m.bond_fdim, 0, main);
   if (m.depth > 1) P.pk.enc_wh = pack(c, m.enc_wh, 0, H, 0, H, 0, main);
   P.pk.enc_wo = pack(c, m.enc_wo, 0, H, 0, m.atom_fdim, H, main);
+  P.pk.dif_wi = pack(c, m.dif_wi, 0, H, 0, H, 0, main);
+  if (m.diff_depth > 1) P.pk.dif_wh = pack(c, m.dif_wh, 0, H, 0, H, m.bond_fdim, main);
+  if (m.diff_depth > 0) P.pk.dif_wo = pack(c, m.dif_wo, 0, H, 0, H, H, main);
+  for (int li = 0; li < m.n_ffn; ++li) P.pk.ffn[li] = pack(c, m.ffn[li], 0, m.ffn[li].out, 0, m.ffn[li].in, 0, main);
+  flush_packs(c, main);                                  // every forward weight in one launch
   hipStream_t rs = c.use_aux ? c.s.aux : main;
   if (c.launch && c.use_aux) c.fail(stream_wait(c.s.aux, main));
   const uint64_t s_r = site_seed(s.seed, 1), s_p = site_seed(s.seed, 2);
@@ -343,18 +360,18 @@ void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
   else mpn_forward(c, m, s.r, P.pk, p, s_r, P.r, rs);
   mpn_forward(c, m, s.p, P.pk, p, s_p, P.p, main);
   if (c.launch && c.use_aux) c.fail(stream_wait(main, c.s.aux));
-  P.pk.dif_wi = pack(c, m.dif_wi, 0, H, 0, H, 0, main);
-  if (m.diff_depth > 1) P.pk.dif_wh = pack(c, m.dif_wh, 0, H, 0, H, m.bond_fdim, main);
-  if (m.diff_depth > 0) P.pk.dif_wo = pack(c, m.dif_wo, 0, H, 0, H, H, main);
   mpndiff_forward(c, m, s.p, P.pk, p, site_seed(s.seed, 3), P.p.h, P.r.h, s.mode == RR_STEP_DEDUP ? s.amap : nullptr,
                   s.feat, s.F, site_seed(s.seed, 4), P.d, main);
-  for (int li = 0; li < m.n_ffn; ++li) P.pk.ffn[li] = pack(c, m.ffn[li], 0, m.ffn[li].out, 0, m.ffn[li].in, 0, main);
   ffn_forward(c, m, P.pk, s.p.M, p, site_seed(s.seed, 5), P.d.vecs, P.d.ld_vecs, s.out, P.f, main);
   P.fwd_end = c.ar.off;
 }
 
 // ------------------------------------------------------------------------------------------------ backward pieces
 struct EncGrads { float *wi, *bi, *wh, *bh, *wo, *bo; };
+struct PackedT {                     // transposed weights of the input-gradient GEMMs (dX = dZ * W): packed in one launch
+  Packed ffn[RR_MAX_FFN];
+  Packed dif_wo_x, dif_wo_a, dif_wh, dif_wi, enc_wh, enc_wo;
+};
 
 // d message = adjoint of the bond message (one gather over b2b_t; row 0 from the GEMM's weighted column sums)
 float* bond_adjoint(Ctx& c, const rr_graph& g, int H, const float* d_min, const float* part, hipStream_t st) {
@@ -499,7 +516,7 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
 // adjoint of mpndiff_forward -> d_x [nA, H]
 float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, const DiffSaved& S, const float* x, const float* x_sub,
                         const int32_t* x_sub_idx, const float* dvecs, int64_t ld_dvecs, int F, uint64_t out_seed,
-                        const rr_grads& G) {
+                        const rr_grads& G, const PackedT& T) {
   const int H = m.H, depth = m.diff_depth, FB = m.bond_fdim;
   const float ks = 1.0f / (1.0f - p);
   hipStream_t st = c.s.main;
@@ -508,8 +525,7 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
   float* d_x = nullptr;
   float* d_inp = nullptr;
   if (depth > 0) {
-    const Packed wo_x = pack(c, m.dif_wo, 1, H, 0, H, 0, st);
-    const Packed wo_a = pack(c, m.dif_wo, 1, H, H, H, 0, st);
+    const Packed wo_x = T.dif_wo_x, wo_a = T.dif_wo_a;
     float* dz_o = c.ar.f(g.nA, H);
     d_x = c.ar.f(g.nA, H);
     {
@@ -537,8 +553,7 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
     gather_sum(c, d_a, g.nA, H, g.a2a_t, g.nA, g.K, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nA), r4(H));
     const float* dzs[MAXD];
     int ndz = 0;
-    Packed wh_t;
-    if (depth > 1) wh_t = pack(c, m.dif_wh, 1, H, 0, H, 0, st);
+    const Packed wh_t = T.dif_wh;
     for (int it = depth - 2; it >= 0; --it) {
       float* dz = c.ar.f(g.nA, H);
       float* d_a2 = c.ar.f(g.nA, H);
@@ -567,7 +582,7 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
     w.x1 = x; w.ldx1 = H; w.k1 = H; w.x1_sub = x_sub; w.ldx1_sub = H; w.x1_sub_idx = x_sub_idx;
     wgrad(c, w);
   }
-  const Packed wi_t = pack(c, m.dif_wi, 1, H, 0, H, 0, st);
+  const Packed wi_t = T.dif_wi;
   rr_linear_args a = LA(g.nA, H);
   a.a1 = d_inp; a.lda1 = H; a.k1 = H; set_w(a, wi_t);
   if (depth == 0) {
@@ -581,8 +596,15 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
 }
 
 // adjoint of ffn_forward -> d vecs [M, H] (the readout columns only)
+// rows of the transposed pack of FFN layer li (= input columns whose gradient is formed): the first layer only
+// needs the readout columns (the appended feature columns are inputs without gradient)
+int ffn_dx_rows(const rr_model& m, int li) {
+  if (li == m.n_ffn - 1 || li > 0) return m.ffn[li].in;
+  return m.n_ffn > 1 ? m.H : m.ffn[li].in;
+}
+
 float* ffn_backward(Ctx& c, const rr_model& m, int64_t M, float p, const FfnSaved& S, const float* dout, const rr_grads& G,
-                    int64_t* ld_out) {
+                    const PackedT& T, int64_t* ld_out) {
   const float ks = 1.0f / (1.0f - p);
   hipStream_t st = c.s.main;
   const int nl = m.n_ffn;
@@ -598,12 +620,11 @@ float* ffn_backward(Ctx& c, const rr_model& m, int64_t M, float p, const FfnSave
     w.x1 = S.hs[nl - 1]; w.ldx1 = S.ld_hs[nl - 1]; w.k1 = L.in;
     wgrad(c, w);
   }
-  const int dx_cols = nl > 1 ? m.H : L.in;               // first layer: only the readout columns carry a gradient
-  int ncur = (nl > 1) ? L.in : dx_cols;
+  const int ncur = ffn_dx_rows(m, nl - 1);
   float* dx = c.ar.f(M, r4(ncur));
   int64_t ld_dx = r4(ncur);
   {
-    const Packed wt = pack(c, L, 1, ncur, 0, L.out, 0, st);
+    const Packed wt = T.ffn[nl - 1];
     rr_linear_args a = LA(M, ncur);
     a.a1 = d; a.lda1 = L.out; a.k1 = L.out; set_w(a, wt); a.c = dx; a.ldc = ld_dx;
     RR_TRY(c, rr_linear_f32(&a, st));
@@ -617,9 +638,9 @@ float* ffn_backward(Ctx& c, const rr_model& m, int64_t M, float p, const FfnSave
       w.x1 = S.hs[li]; w.ldx1 = S.ld_hs[li]; w.k1 = Lh.in;
       wgrad(c, w);
     }
-    const int nin = li > 0 ? Lh.in : dx_cols;
+    const int nin = ffn_dx_rows(m, li);
     float* dn = c.ar.f(M, r4(nin));
-    const Packed wt = pack(c, Lh, 1, nin, 0, Lh.out, 0, st);
+    const Packed wt = T.ffn[li];
     rr_linear_args a = LA(M, nin);
     a.a1 = dx; a.lda1 = ld_dx; a.k1 = Lh.out; a.a_mask = y; a.ld_mask = S.ld_hs[li + 1]; a.mask_scale = ks;
     set_w(a, wt); a.c = dn; a.ldc = r4(nin);
@@ -635,10 +656,23 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
   const int H = m.H;
   const float p = s.drop_p;
   hipStream_t main = c.s.main;
+  // every transposed weight of the backward in ONE pack launch
+  PackedT T;
+  memset(&T, 0, sizeof(T));
+  for (int li = 0; li < m.n_ffn; ++li) T.ffn[li] = pack(c, m.ffn[li], 1, ffn_dx_rows(m, li), 0, m.ffn[li].out, 0, main);
+  if (m.diff_depth > 0) {
+    T.dif_wo_x = pack(c, m.dif_wo, 1, H, 0, H, 0, main);
+    T.dif_wo_a = pack(c, m.dif_wo, 1, H, H, H, 0, main);
+  }
+  if (m.diff_depth > 1) T.dif_wh = pack(c, m.dif_wh, 1, H, 0, H, 0, main);
+  T.dif_wi = pack(c, m.dif_wi, 1, H, 0, H, 0, main);
+  if (m.depth > 1) T.enc_wh = pack(c, m.enc_wh, 1, H, 0, H, 0, main);
+  T.enc_wo = pack(c, m.enc_wo, 1, H, m.atom_fdim, H, 0, main);
+  flush_packs(c, main);
   int64_t ld_dvecs = 0;
-  float* dvecs = ffn_backward(c, m, s.p.M, p, P.f, dout, G, &ld_dvecs);
+  float* dvecs = ffn_backward(c, m, s.p.M, p, P.f, dout, G, T, &ld_dvecs);
   const int32_t* xsi = s.mode == RR_STEP_DEDUP ? s.amap : nullptr;
-  float* d_diff = mpndiff_backward(c, m, s.p, p, P.d, P.p.h, P.r.h, xsi, dvecs, ld_dvecs, s.F, site_seed(s.seed, 4), G);
+  float* d_diff = mpndiff_backward(c, m, s.p, p, P.d, P.p.h, P.r.h, xsi, dvecs, ld_dvecs, s.F, site_seed(s.seed, 4), G, T);
   // de-duplicated reactants: d r_h[u] = -(sum over the copies of atom u of d_diff) (fixed-order segment sum)
   const float* d_r = d_diff;
   if (s.mode == RR_STEP_DEDUP) {
@@ -646,9 +680,7 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
     gather_sum(c, d_diff, s.p.nA, H, s.amap_t, s.r.nA, s.amap_t_cols, H, t, H, main);
     d_r = t;
   }
-  Packed wh_t;
-  if (m.depth > 1) wh_t = pack(c, m.enc_wh, 1, H, 0, H, 0, main);
-  const Packed wo_t = pack(c, m.enc_wo, 1, H, m.atom_fdim, H, 0, main);
+  const Packed wh_t = T.enc_wh, wo_t = T.enc_wo;
   EncGrads E;
   E.wi = G.w[RR_G_ENC_WI]; E.bi = G.b[RR_G_ENC_WI]; E.wh = G.w[RR_G_ENC_WH]; E.bh = G.b[RR_G_ENC_WH];
   E.wo = G.w[RR_G_ENC_WO]; E.bo = G.b[RR_G_ENC_WO];
@@ -705,7 +737,7 @@ void rr_abi_plan_struct_sizes(size_t* graph, size_t* model, size_t* step, size_t
 size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
   if (check(model, step) != RR_OK) return 0;
   Ctx c;
-  c.launch = false; c.status = RR_OK; c.ar.base = nullptr; c.ar.off = 0; c.ar.cap = 0; c.ar.overflow = false;
+  c.launch = false; c.status = RR_OK; c.ar.base = nullptr; c.ar.off = 0; c.ar.cap = 0; c.ar.overflow = false; c.npq = 0;
   c.use_side = c.use_aux = false;
   Plan P;
   memset(&P, 0, sizeof(P));
@@ -721,7 +753,7 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   if (st != RR_OK) return st;
   RR_CHECK_ARG(step->workspace && rr_aligned16(step->workspace));
   Ctx c;
-  c.launch = true; c.status = RR_OK;
+  c.launch = true; c.status = RR_OK; c.npq = 0;
   c.ar.base = static_cast<char*>(step->workspace); c.ar.off = 0; c.ar.cap = step->workspace_bytes; c.ar.overflow = false;
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
@@ -753,7 +785,7 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
     RR_CHECK_ARG(!needed || grads->w[i]);
   }
   Ctx c;
-  c.launch = false; c.status = RR_OK;
+  c.launch = false; c.status = RR_OK; c.npq = 0;
   c.ar.base = static_cast<char*>(step->workspace); c.ar.off = 0; c.ar.cap = step->workspace_bytes; c.ar.overflow = false;
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;

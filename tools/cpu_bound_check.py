@@ -19,5 +19,17 @@ for i in range(steps):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+# the same with an EMPTY queue before every step: the host's own cost of issuing one step (the figure above also
+# contains the time the host spends blocked in the runtime once it is several steps ahead of the GPU)
+alone = []
+for i in range(steps):
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    R.train_step(R.pool[i % 6])
+    alone.append(time.perf_counter() - a)
+torch.cuda.synchronize()
+alone.sort()
+print(f"{preset}: host cost of issuing one step into an empty queue: median {1e3 * alone[len(alone) // 2]:.2f} ms, "
+      f"min {1e3 * alone[0]:.2f} ms")
 print(f"{preset}: enqueue {1e3 * (t1 - t0) / steps:.2f} ms/step, total {1e3 * (t2 - t0) / steps:.2f} ms/step, "
       f"drain after last enqueue {1e3 * (t2 - t1):.2f} ms")
