@@ -362,9 +362,11 @@ def main():
         if torch.cuda.device_count() < 1:
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
         try:
-            workers = 1 if under_profiler() else max(1, args.shard_workers // max(1, world))
-            log(f"packing {args.epoch_steps} distinct steps into shard files ({workers} CPU process(es))")
-            shard_dir, shard_paths, t_shards = build_shards(args.epoch_steps, 50000 + 100000 * rank, cfg["queries"],
+            # --epoch-steps distinct steps over the whole job: every rank packs and streams its own share
+            n_epoch = (args.epoch_steps + world - 1) // world
+            workers = 1 if under_profiler() else max(1, min(args.shard_workers, n_epoch))
+            log(f"packing {n_epoch} distinct steps per rank into shard files ({workers} CPU process(es))")
+            shard_dir, shard_paths, t_shards = build_shards(n_epoch, 50000 + 100000 * rank, cfg["queries"],
                                                             cfg["cands"], args.pad_width, workers)
             log(f"shards ready in {t_shards:.1f}s: {sum(os.path.getsize(p) for p in shard_paths) / 1e9:.2f} GB in {shard_dir}")
         except Exception as e:                            # noqa: BLE001  (e.g. no space left): report, do not hide
@@ -509,7 +511,8 @@ def main():
                 dist.all_reduce(te, op=dist.ReduceOp.MAX)
             e_secs = float(te.item())
             qps_e = world * n * cfg["queries"] / e_secs
-            epoch = dict(epoch_queries_per_s=round(qps_e, 2), ms_per_step=round(e_secs / n * 1e3, 3), distinct_steps=n,
+            epoch = dict(epoch_queries_per_s=round(qps_e, 2), ms_per_step=round(e_secs / n * 1e3, 3), distinct_steps=n * world,
+                         distinct_steps_per_rank=n,
                          vs_resident=round(qps_e / (world * args.steps * cfg["queries"] / elapsed), 4),
                          step_ms=step_stats(e_per), shard_files=len(shard_paths),
                          shard_gb_per_rank=round(sum(os.path.getsize(p) for p in shard_paths) / 1e9, 3),
