@@ -476,7 +476,9 @@ def main():
     if roof:
         roof["peak_at_load_clock"] = load_clock
         roof["traffic_source"] = traffic_src
-        roof["note"] = "timed region; weight-gradient / reactant-encoder streams run concurrently with the main stream"
+        roof["note"] = ("timed region; weight-gradient / reactant-encoder streams run concurrently with the main stream; the "
+                        "steps that carry events (every 5th) issue the same kernels through the per-op entry points, the "
+                        "others through the step plan")
     # isolated pass: the same steps with every kernel serialised on one stream -> per-kernel quality
     roof_iso = roof_g_iso = None
     ktable_iso = {}
@@ -521,7 +523,8 @@ def main():
                          note="every step read once from shard files (page cache -> pinned staging -> one H2D copy per step on a "
                               "copy stream, 3 slots); only the 22 bond columns of f_bonds and the distinct reactants' "
                               "features travel, the rest is rebuilt on the device; same model / optimizer state continues "
-                              "from the timed region")
+                              "from the timed region; no kernel events are recorded in this leg (the timed region pays ~1 % "
+                              "for them), so vs_resident can exceed 1")
             log(f"epoch stream: {e_secs / n * 1e3:.2f} ms/step, {qps_e:.0f} queries/s")
         except Exception as e:                            # noqa: BLE001
             epoch = dict(skipped=f"{type(e).__name__}: {e}")
