@@ -120,6 +120,10 @@ MODEL_CASES = [
     dict(name="H_h64_evidential4", hidden_size=64, mpnn_depth=2, mpnn_diff_depth=2, ffn_depth=3,
          use_bias=True, task_num=4, ffn_last_layer="with_softplus", task_type=None, add_features_dim=1,
          scope=[5, 3], seed=18, wseed=108),
+    # hidden size NOT a multiple of 4 (no 16-byte rows): the generic kernels and the non-fused ReLU-backward branch
+    dict(name="I_h30_d4_mle", hidden_size=30, mpnn_depth=4, mpnn_diff_depth=4, ffn_depth=3, use_bias=True,
+         task_num=1, ffn_last_layer="with_softplus", task_type=None, add_features_dim=1,
+         scope=[6, 9, 4], seed=19, wseed=109),
 ]
 
 
@@ -563,8 +567,11 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(4)
-    if len(sys.argv) > 2 and sys.argv[1] == "--only":      # e.g. --only train_utils
-        globals()["gen_" + sys.argv[2]]()
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":      # e.g. --only train_utils, or --only model:I_h30_d4_mle
+        if sys.argv[2].startswith("model:"):
+            gen_model_case(next(c for c in MODEL_CASES if c["name"] == sys.argv[2][6:]))
+        else:
+            globals()["gen_" + sys.argv[2]]()
         sys.exit(0)
     for case in MODEL_CASES:
         gen_model_case(case)
