@@ -139,7 +139,9 @@ typedef struct rr_linear_args {
                                                        message-passing step (the residual `input +` of mpn.py:95).
                                                        Needs k1 % 4 == 0 and 16-byte aligned rows. */
   const float* w;        int64_t ldw;               /* [N, k1+k2] row-major (nn.Linear.weight), or */
-  int w_packed;                                     /* 1: the zero-padded layout of rr_pack_weight_f32 */
+  int w_packed;                                     /* 1: the zero-padded layout of rr_pack_weight_f32;
+                                                       2: the three-bf16-term images of rr_pack_weights_f32
+                                                          (rr_pack_desc.split): f32 result on the bf16 matrix core */
   const float* bias;                                /* [N] or NULL */
   const float* residual; int64_t ldr;               /* [M, N] or NULL */
   const int32_t* residual_idx;                      /* optional: row m adds residual[residual_idx[m]] (shared `input`
@@ -179,8 +181,14 @@ int rr_pack_weight_f32(const float* src, int64_t ld_src, int transpose, int rows
 typedef struct rr_pack_desc {
   const float* src;  int64_t ld_src;  int transpose, rows, c0, k1, k2;
   float* dst;
+  int split;         /* 0: the f32 layout above.  1: dst (rr_split_weight_bytes(rows, k1, k2) bytes, 16-byte aligned,
+                        rows <= 304) receives every element of L as three bf16 terms t0 + t1 + t2 == L[r, c] EXACTLY
+                        (t0 = bf16(x), t1 = bf16(x - t0), t2 = x - t0 - t1), laid out as the LDS image of each
+                        32-deep k-step of rr_linear_f32's w_packed = 2 path:
+                        [k-step][16-column tile][term][lane 0..63][8 bf16], lane = (k-group of 8) * 16 + column */
 } rr_pack_desc;
 int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream);
+size_t rr_split_weight_bytes(int rows, int k1, int k2);
 
 /* dW[n, k] (+)= sum_m dZ[m,n] * X[m,k],   dbias[n] (+)= sum_m dZ[m,n]
  * dZ[m,n] = dy[m,n] * (mask ? (mask[m,n] > 0) * mask_scale : 1);  X = [X1 | X2] described
@@ -405,7 +413,9 @@ typedef struct rr_model {
 enum { RR_STEP_PLAIN = 0,    /* encoder(r) on the full reactant batch */
        RR_STEP_DEDUP = 1,    /* dropout inactive: `r` holds the DISTINCT reactants, amap / amap_t map product atoms to them */
        RR_STEP_PREFIX = 2 }; /* train mode: `u` holds the distinct reactants, only the deterministic prefix is shared */
-enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2 };
+enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2,
+       RR_PLAN_F32_GEMM = 4 };   /* encoder GEMMs on the f32 matrix core instead of the three-bf16-term path (w_packed = 2);
+                                    forward and backward of a step must agree on it (it changes the workspace layout) */
 
 typedef struct rr_step {
   rr_graph p, r, u;

@@ -40,6 +40,13 @@ class LinearArgs(C.Structure):
     ]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [
+        ("src", c_f32p), ("ld_src", i64), ("transpose", i32), ("rows", i32), ("c0", i32), ("k1", i32), ("k2", i32),
+        ("dst", C.c_void_p), ("split", i32),
+    ]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [
         ("M", i64), ("N", i32),
@@ -58,7 +65,7 @@ class WgradArgs(C.Structure):
 RR_MAX_FFN = 8
 RR_G_FFN0 = 6
 RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
-RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM = 1, 2
+RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM = 1, 2, 4
 
 
 class Graph(C.Structure):
@@ -116,6 +123,7 @@ _SIGS = {
     "rr_linear_colsum_rows": (i64, [i64]),
     "rr_gather_sum_padrow_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, c_f32p, i64, c_stream]),
     "rr_packed_weight_ld": (i64, [i32, i32]),
+    "rr_split_weight_bytes": (C.c_size_t, [i32, i32, i32]),
     "rr_pack_weight_f32": (i32, [c_f32p, i64, i32, i32, i32, i32, i32, c_f32p, c_stream]),
     "rr_pack_weights_f32": (i32, [C.c_void_p, i32, c_stream]),
     "rr_linear_wgrad_workspace_bytes": (C.c_size_t, [i64, i32, i32]),
@@ -163,7 +171,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

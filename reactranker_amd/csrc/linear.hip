@@ -601,6 +601,7 @@ struct PackMany {
 };
 __global__ void __launch_bounds__(256) pack_weights_kernel(const PackMany P) {
   const rr_pack_desc& q = P.d[blockIdx.y];
+  if (q.split) return;                                 // pack_split_kernel's
   const int k1p = r16(q.k1), ldd = r16(q.k1) + r16(q.k2);
   const int64_t total = static_cast<int64_t>(q.rows) * ldd;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -614,6 +615,355 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackMany P) {
       v = q.transpose ? q.src[static_cast<int64_t>(lc) * q.ld_src + q.c0 + r] : q.src[static_cast<int64_t>(r) * q.ld_src + q.c0 + lc];
     q.dst[e] = v;
   }
+}
+
+// ------------------------------------------------------------------------ split path (3 x bf16 terms, 6 products)
+// The same GEMM on the bf16 matrix core without giving up f32 accuracy.  Every f32 operand is written EXACTLY as
+// the sum of three bf16 terms, x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1: the two
+// remainders are exact in f32 and the last one has at most 8 significant bits left), and
+//     x * w  =  x0 w0 + (x0 w1 + x1 w0) + (x0 w2 + x1 w1 + x2 w0)  +  terms below 2^-24 |x w|
+// is accumulated in f32 by six v_mfma_f32_16x16x32_bf16 per 32-deep k-step, smallest terms first.  bf16 x bf16
+// products are exact in f32, and the sum of a k-step is rounded once instead of after every fmaf, so the error
+// against an f64 GEMM is at or BELOW that of the f32 MFMA chain (tests/test_gpu_split.py measures both).  Six bf16
+// MFMAs cost 6/16 of the f32 MFMA's cycles for the same k: the kernel moves from MFMA-bound to HBM-bound.
+//
+// Geometry: workgroup = 8 waves x 16 rows = 128 rows x up to 304 output columns; the activation operand goes
+// global -> registers (each lane loads the 8 consecutive k of ITS row that the MFMA layout hands it, fixes them up
+// - gather / subtract / ReLU mask - and splits them: every element is converted exactly once); the weight terms
+// are pre-split by rr_pack_weights (w_packed = 2) into the exact LDS image of a k-step (per column tile and term:
+// 64 lanes x 16 B, lane-linear) and stream L2 -> LDS by LDS-DMA, double buffered (2 x 57 KB: one workgroup per CU).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SK = 32;                    // k per step
+#ifndef RR_SPLIT_WAVES
+#define RR_SPLIT_WAVES 12
+#endif
+constexpr int S_WAVES = RR_SPLIT_WAVES;       // 12 waves = 3 per SIMD (<= 168 registers), 192 rows per workgroup
+constexpr int S_THREADS = 64 * S_WAVES;
+constexpr int S_BM = 16 * S_WAVES;
+
+__host__ __device__ constexpr int r32(int k) { return (k + 31) & ~31; }
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// exact three-term split of two floats (packed bf16 pairs, low half = x)
+__device__ __forceinline__ void split_pair(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = cvt_pk_bf16(x, y);
+  float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
+  p1 = cvt_pk_bf16(rx, ry);
+  rx -= __uint_as_float(p1 << 16);
+  ry -= __uint_as_float(p1 & 0xffff0000u);
+  p2 = cvt_pk_bf16(rx, ry);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int NT, int MODE>
+__global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearParams P) {
+  constexpr int BN = 16 * NT;
+  constexpr int PANEL = NT * 3 * 1024;                 // bytes of one k-step's weight image
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const bias_s = reinterpret_cast<float*>(smem + 2 * PANEL);
+
+  const rr_linear_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fkq = lane >> 4;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * S_BM;
+  const int64_t m = m0 + wave * 16 + fr;
+  const bool row_ok = m < a.M;
+  const int64_t mc = row_ok ? m : a.M - 1;
+  const float* const dummy = a.w;                      // any valid, 16-byte aligned GLOBAL address (keeps the loads global_load)
+  const float* rowp1 = nullptr;
+  const float* rowp2 = nullptr;
+  const float* subp = nullptr;                         // MODE 1: subtract source, MODE 2: mask source
+  {
+    const bool g1 = a.k1 > 0 && a.a1_idx != nullptr;
+    const bool g2 = MODE == 1 && a.k1 > 0 && a.a1_sub != nullptr && a.a1_sub_idx != nullptr;
+    const int32_t j1 = g1 ? ldgi(a.a1_idx + mc) : 0;
+    const int32_t j2 = g2 ? ldgi(a.a1_sub_idx + mc) : 0;
+    if (row_ok) {
+      if (a.k1 > 0) {
+        if (g1) {
+          if (j1 >= 0) rowp1 = a.a1 + static_cast<int64_t>(j1) * a.lda1;
+        } else {
+          rowp1 = a.a1 + m * a.lda1;
+        }
+        if (MODE == 1 && a.a1_sub) {
+          if (g2) {
+            if (j2 >= 0) subp = a.a1_sub + static_cast<int64_t>(j2) * a.lda1_sub;
+          } else {
+            subp = a.a1_sub + m * a.lda1_sub;
+          }
+        }
+        if (MODE == 2) subp = a.a_mask + m * a.ld_mask;
+      }
+      if (a.k2 > 0) rowp2 = a.a2 + m * a.lda2;
+    }
+  }
+  float* dzrow = nullptr;                              // MODE 2 side output: dz_out (+)= masked operand
+  if (MODE == 2 && a.dz_out && row_ok) dzrow = a.dz_out + m * a.ld_dz;
+
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  const float* const wlane = a.w + lane * 4;           // 16 B per lane inside a 1 KiB block
+  const uint32_t lds0 = rr_lds_addr(reinterpret_cast<const float*>(smem));
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4(0.f);
+
+  const int nk = P.t1 + P.t2;
+  // operand chunks in flight: two k-steps (slot = step & 1), so a load has two MFMA blocks to land; the weight image one
+  f32x4 ra[2][2], rs[2][2];
+  u32x4 x0, x1, x2;                                    // the three bf16 terms of the current step's operand
+
+  auto issue_x = [&](int s, int slot) {                // pure loads (unconditional, from a selected address)
+    const bool seg1 = s < P.t1;
+    const int kl = (seg1 ? s : s - P.t1) * SK + fkq * 8;
+    const float* p = seg1 ? rowp1 : rowp2;
+    const int ks = seg1 ? a.k1 : a.k2;
+    ra[slot][0] = ldg4((p != nullptr && kl < ks) ? p + kl : dummy);
+    ra[slot][1] = ldg4((p != nullptr && kl + 4 < ks) ? p + kl + 4 : dummy);
+    if (MODE != 0) {
+      const bool oks = seg1 && subp != nullptr;
+      rs[slot][0] = ldg4((oks && kl < ks) ? subp + kl : dummy);
+      rs[slot][1] = ldg4((oks && kl + 4 < ks) ? subp + kl + 4 : dummy);
+    }
+  };
+  auto issue_w = [&](int s) {                          // weight image of step s: NT * 3 LDS-DMA blocks of 1 KiB over the waves
+    const float* src = wlane + static_cast<int64_t>(s) * (PANEL / 4);
+    const uint32_t dst = lds0 + (s & 1) * PANEL;
+#pragma unroll
+    for (int b0 = 0; b0 < NT * 3; b0 += S_WAVES) {
+      const int b = b0 + uwave;
+      if (b < NT * 3) rr_glds16(src + b * 256, dst + b * 1024);
+    }
+  };
+  auto fixup = [&](int s, int slot) {                  // first use of the loads: selects, mask / subtract, split
+    const bool seg1 = s < P.t1;
+    const int kl = (seg1 ? s : s - P.t1) * SK + fkq * 8;
+    const float* p = seg1 ? rowp1 : rowp2;
+    const int ks = seg1 ? a.k1 : a.k2;
+    const bool ok = (p != nullptr);
+    f32x4 v0, v1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v0[e] = (ok && kl + e < ks) ? ra[slot][0][e] : 0.f;
+      v1[e] = (ok && kl + 4 + e < ks) ? ra[slot][1][e] : 0.f;
+    }
+    if (MODE == 1) {
+      const bool oks = seg1 && (subp != nullptr);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] -= (oks && kl + e < ks) ? rs[slot][0][e] : 0.f;
+        v1[e] -= (oks && kl + 4 + e < ks) ? rs[slot][1][e] : 0.f;
+      }
+    }
+    if (MODE == 2) {
+      const bool oks = seg1 && (subp != nullptr);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = (oks && kl + e < ks && rs[slot][0][e] > 0.f) ? v0[e] * a.mask_scale : 0.f;
+        v1[e] = (oks && kl + 4 + e < ks && rs[slot][1][e] > 0.f) ? v1[e] * a.mask_scale : 0.f;
+      }
+    }
+    uint32_t t0, t1, t2;
+    split_pair(v0.x, v0.y, t0, t1, t2); x0.x = t0; x1.x = t1; x2.x = t2;
+    split_pair(v0.z, v0.w, t0, t1, t2); x0.y = t0; x1.y = t1; x2.y = t2;
+    split_pair(v1.x, v1.y, t0, t1, t2); x0.z = t0; x1.z = t1; x2.z = t2;
+    split_pair(v1.z, v1.w, t0, t1, t2); x0.w = t0; x1.w = t1; x2.w = t2;
+    if (MODE == 2) {                                   // side output (k1 % 4 == 0: chunks are whole).  Stored HERE, after the
+      if (dzrow != nullptr && seg1) {                  // step's load wait: the store then has the whole next MFMA block to retire
+        if (kl < ks) *reinterpret_cast<f32x4*>(dzrow + kl) = v0;
+        if (kl + 4 < ks) *reinterpret_cast<f32x4*>(dzrow + kl + 4) = v1;
+      }
+    }
+  };
+  auto mfma_block = [&](int s) {
+    const u32x4* Ws = reinterpret_cast<const u32x4*>(smem + (s & 1) * PANEL) + lane;
+    const bf16x8 b0 = as_bf16x8(x0), b1 = as_bf16x8(x1), b2 = as_bf16x8(x2);
+    // the three weight terms of tile j+1 are read while the six MFMAs of tile j run (pinned with sched_group_barrier:
+    // left alone, the scheduler issues each ds_read right in front of its first use and waits for it)
+    u32x4 wa = Ws[0], wb = Ws[64], wc = Ws[128];
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const bf16x8 w0 = as_bf16x8(wa), w1 = as_bf16x8(wb), w2 = as_bf16x8(wc);
+      if (j + 1 < NT) {
+        wa = Ws[((j + 1) * 3 + 0) * 64];
+        wb = Ws[((j + 1) * 3 + 1) * 64];
+        wc = Ws[((j + 1) * 3 + 2) * 64];
+      }
+      f32x4 c = acc[j];
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, b0, c, 0, 0, 0);   // smallest terms first
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, b1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, b2, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, b0, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, b1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, b0, c, 0, 0, 0);
+      acc[j] = c;
+      if (j + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+  };
+  // one k-step with compile-time slots.  vmcnt retires in issue order: the operand loads of step s+2 are issued AFTER the
+  // weight image of step s+1, so "all but the youngest NX" = image landed, step s+1's chunks landed, step s+2's in flight.
+  constexpr int NX = MODE == 0 ? 2 : 4;                // vector-memory instructions of one issue_x
+  auto step = [&](int s, int slot) {
+    const bool more = s + 1 < nk, more2 = s + 2 < nk;
+    if (more) issue_w(s + 1);
+    if (more2) issue_x(s + 2, slot);
+    mfma_block(s);
+    if (more2) {
+      if (NX == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      rr_wait_vm0();
+    }
+    if (more) fixup(s + 1, slot ^ 1);
+    __syncthreads();
+  };
+
+  if (tid < BN / 4) {
+    const int n = tid * 4;
+    *reinterpret_cast<f32x4*>(bias_s + tid * 4) = ldg4((a.bias && n < a.N) ? a.bias + n : dummy);
+  }
+  issue_w(0);
+  issue_x(0, 0);
+  if (nk > 1) issue_x(1, 1);
+  rr_wait_vm0();
+  fixup(0, 0);
+  __syncthreads();
+
+  for (int s = 0; s < nk; s += 2) {
+    step(s, 0);
+    if (s + 1 < nk) step(s + 1, 1);
+  }
+
+  // ---- epilogue: the accumulator layout is that of linear_fast_kernel (a lane holds 4 consecutive columns of one row)
+  const int nq = fkq * 4;
+  float* crow = a.c + mc * a.ldc;
+  const float* rrow = nullptr;
+  if (a.residual) {
+    const int64_t rr = a.residual_idx ? static_cast<int64_t>(a.residual_idx[mc]) : mc;
+    if (rr >= 0) rrow = a.residual + rr * a.ldr;
+  }
+  const bool has_bias = a.bias != nullptr;
+  const bool relu = a.act == RR_ACT_RELU;
+  auto finish = [&](f32x4 v, int n) -> f32x4 {
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (P.drop_thr != 0u) {
+      const uint64_t base = static_cast<uint64_t>(m) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
+      const uint32_t w = rr_hash_group(a.drop_seed, base >> 2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rr_hash_lane(w, e) >= P.drop_thr ? v[e] * P.keep_scale : 0.f;
+    }
+    if (row_ok && n < a.N) *reinterpret_cast<f32x4*>(crow + n) = v;
+    return v;
+  };
+  float* prow = a.c_pre ? a.c_pre + mc * a.ld_pre : nullptr;
+  const bool cs_on = a.colsum_partial != nullptr;
+  const float wrow = (cs_on && row_ok) ? a.colsum_w[mc] : 0.f;
+  float* const cs_lds = reinterpret_cast<float*>(smem);    // [waves][BN], the (now idle) weight image
+  {
+    const bool res_ok = rrow != nullptr;
+    const float* rbase = res_ok ? rrow : dummy;
+    constexpr int D = 4;
+    f32x4 ring[D + 1];
+    auto ldres = [&](int tc) {
+      const int n = tc * 16 + nq;
+      return ldg4(rbase + ((res_ok && n < a.N) ? n : 0));
+    };
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+      if (t < NT) ring[t] = ldres(t);
+#pragma unroll
+    for (int tc = 0; tc < NT; ++tc) {
+      const int n = tc * 16 + nq;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + tc * 16 + nq);
+      f32x4 v = acc[tc];
+      const f32x4 vb = v + b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = has_bias ? vb[e] : v[e];
+      const f32x4 vr = v + ring[tc % (D + 1)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = res_ok ? vr[e] : v[e];
+      if (tc + D < NT) ring[(tc + D) % (D + 1)] = ldres(tc + D);
+      if (prow != nullptr && row_ok && n < a.N) *reinterpret_cast<f32x4*>(prow + n) = v;
+      const f32x4 stored = finish(v, n);
+      if (cs_on) {
+        f32x4 t = stored * wrow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = t[e];
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));   // row_shr:1
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));   // row_shr:2
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));   // row_shr:4
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));   // row_shr:8
+          t[e] = x;
+        }
+        if (fr == 15) *reinterpret_cast<f32x4*>(cs_lds + wave * BN + tc * 16 + nq) = t;
+      }
+    }
+  }
+  if (cs_on) {                                         // one partial row per 64 rows (rr_linear_colsum_rows) = per 4 waves
+    __syncthreads();
+    static_assert(S_WAVES % 4 == 0 && (S_WAVES / 4) * (BN / 4) <= S_THREADS, "colsum slices");
+    if (tid < (S_WAVES / 4) * (BN / 4)) {
+      const int h = tid / (BN / 4);
+      const int q = tid - h * (BN / 4);
+      const int n = q * 4;
+      const float* base = cs_lds + h * 4 * BN + q * 4;
+      const f32x4 s01 = ld4(base) + ld4(base + BN);
+      const f32x4 s23 = ld4(base + 2 * BN) + ld4(base + 3 * BN);
+      if (n < a.N && m0 + h * 64 < a.M)
+        *reinterpret_cast<f32x4*>(a.colsum_partial + (static_cast<int64_t>(blockIdx.x) * (S_WAVES / 4) + h) * a.ld_partial + n) = s01 + s23;
+    }
+  }
+}
+
+// weight terms of the split path: dst = [k-step][column tile][term 0..2][lane 0..63][8 bf16], the LDS image of a k-step
+__device__ __forceinline__ void split_one(float x, uint16_t& t0, uint16_t& t1, uint16_t& t2) {
+  uint32_t p0, p1, p2;
+  split_pair(x, 0.f, p0, p1, p2);
+  t0 = static_cast<uint16_t>(p0 & 0xffffu);
+  t1 = static_cast<uint16_t>(p1 & 0xffffu);
+  t2 = static_cast<uint16_t>(p2 & 0xffffu);
+}
+__host__ __device__ constexpr int split_nt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : 19); }
+
+__device__ __forceinline__ void pack_split_elem(const rr_pack_desc& q, int64_t e) {
+  const int nt = split_nt(q.rows);
+  const int t1 = r32(q.k1) / SK;
+  const int el = static_cast<int>(e & 7), lane = static_cast<int>((e >> 3) & 63);
+  const int64_t blk = e >> 9;                          // (s * nt + j)
+  const int j = static_cast<int>(blk % nt), s = static_cast<int>(blk / nt);
+  const int n = j * 16 + (lane & 15);
+  const int kk = (s < t1 ? s : s - t1) * SK + (lane >> 4) * 8 + el;
+  int lc = -1;
+  if (s < t1) {
+    if (kk < q.k1) lc = kk;
+  } else if (kk < q.k2) {
+    lc = q.k1 + kk;
+  }
+  float v = 0.f;
+  if (lc >= 0 && n < q.rows)
+    v = q.transpose ? q.src[static_cast<int64_t>(lc) * q.ld_src + q.c0 + n] : q.src[static_cast<int64_t>(n) * q.ld_src + q.c0 + lc];
+  uint16_t* d = reinterpret_cast<uint16_t*>(q.dst) + blk * 3 * 512 + lane * 8 + el;
+  split_one(v, d[0], d[512], d[1024]);
+}
+
+__global__ void __launch_bounds__(256) pack_split_kernel(const PackMany P) {
+  const rr_pack_desc& q = P.d[blockIdx.y];
+  if (!q.split) return;
+  const int64_t total = static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * split_nt(q.rows) * 512;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) pack_split_elem(q, e);
 }
 
 // ======================================================================== weight gradient
@@ -1140,6 +1490,27 @@ int launch_linear(const LinearParams& P, hipStream_t s, bool fast) {
 
 inline bool vec_ok(const float* p, int64_t ld) { return p && rr_aligned16(p) && (ld % 4 == 0); }
 
+template <int NT, int MODE>
+int launch_split_one(const LinearParams& P, hipStream_t s) {
+  constexpr int smem = 2 * NT * 3 * 1024 + 16 * NT * 4;
+  static bool configured = false;                      // > 64 KiB of LDS has to be asked for once per kernel
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NT, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return RR_ERR_LAUNCH;
+    configured = true;
+  }
+  const unsigned grid = static_cast<unsigned>((P.a.M + S_BM - 1) / S_BM);
+  linear_split_kernel<NT, MODE><<<grid, S_THREADS, smem, s>>>(P);
+  return rr_launch_status();
+}
+template <int NT>
+int launch_split(const LinearParams& P, hipStream_t s) {
+  if (P.a.a_mask) return launch_split_one<NT, 2>(P, s);
+  if (P.a.a1_sub) return launch_split_one<NT, 1>(P, s);
+  return launch_split_one<NT, 0>(P, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1155,7 +1526,9 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   const rr_linear_args& a = *args;
   RR_CHECK_ARG(a.M >= 0 && a.N >= 1 && a.k1 >= 0 && a.k2 >= 0 && a.k1 + a.k2 >= 1);
   RR_CHECK_ARG(a.w && a.c && a.ldc >= a.N);
-  RR_CHECK_ARG(a.w_packed ? (a.ldw == r16(a.k1) + r16(a.k2) && rr_aligned16(a.w)) : (a.ldw >= a.k1 + a.k2));
+  RR_CHECK_ARG(a.w_packed >= 0 && a.w_packed <= 2);
+  RR_CHECK_ARG(a.w_packed == 2 ? rr_aligned16(a.w)
+                               : (a.w_packed ? (a.ldw == r16(a.k1) + r16(a.k2) && rr_aligned16(a.w)) : (a.ldw >= a.k1 + a.k2)));
   RR_CHECK_ARG(a.k1 == 0 || (a.a1 && a.lda1 >= a.k1));
   RR_CHECK_ARG(a.k2 == 0 || (a.a2 && a.lda2 >= a.k2));
   RR_CHECK_ARG(!a.a1_sub || (a.k1 > 0 && a.lda1_sub >= a.k1));
@@ -1205,6 +1578,15 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
     RR_CHECK_ARG(a.colsum_w && a.ld_partial >= a.N);
     if (!fast || !vec_ok(a.colsum_partial, a.ld_partial)) return RR_ERR_ALIGN;
   }
+  if (a.w_packed == 2) {                              // split terms only exist in the straight-line geometry
+    if (!fast || a.N > 304 || a.M >= (int64_t(1) << 31) * S_BM) return RR_ERR_ALIGN;
+    if (a.dz_accumulate) return RR_ERR_UNSUPPORTED;
+    P.t1 = r32(a.k1) / SK;
+    P.t2 = r32(a.k2) / SK;
+    if (a.N <= 64) return launch_split<4>(P, s);
+    if (a.N <= 160) return launch_split<10>(P, s);
+    return launch_split<19>(P, s);
+  }
   if (a.N <= 64) return launch_linear<4>(P, s, fast);
   if (a.N <= 160) return launch_linear<10>(P, s, fast);
   return launch_linear<19>(P, s, fast);
@@ -1223,21 +1605,34 @@ int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
   RR_CHECK_ARG(descs && n >= 0 && n <= RR_MAX_PACK);
   if (n == 0) return RR_OK;
   PackMany P;
-  int64_t biggest = 0;
+  int64_t biggest = 0, biggest_split = 0;
   for (int i = 0; i < n; ++i) {
     const rr_pack_desc& q = descs[i];
     RR_CHECK_ARG(q.src && q.dst && q.rows >= 1 && q.c0 >= 0 && q.k1 >= 0 && q.k2 >= 0 && q.k1 + q.k2 >= 1 && q.ld_src >= 1);
+    RR_CHECK_ARG(q.split == 0 || (q.split == 1 && q.rows <= 304 && rr_aligned16(q.dst)));
     P.d[i] = q;
-    const int64_t total = static_cast<int64_t>(q.rows) * (r16(q.k1) + r16(q.k2));
-    if (total > biggest) biggest = total;
+    const int64_t total = q.split ? static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * split_nt(q.rows) * 512
+                                  : static_cast<int64_t>(q.rows) * (r16(q.k1) + r16(q.k2));
+    if (total > (q.split ? biggest_split : biggest)) (q.split ? biggest_split : biggest) = total;
   }
   for (int i = n; i < RR_MAX_PACK; ++i) P.d[i] = descs[0];
-  dim3 grid(static_cast<unsigned>(rr_grid_for(biggest, 256, 64)), static_cast<unsigned>(n));
-  pack_weights_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
+  if (biggest > 0) {
+    dim3 grid(static_cast<unsigned>(rr_grid_for(biggest, 256, 64)), static_cast<unsigned>(n));
+    pack_weights_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
+  }
+  if (biggest_split > 0) {
+    dim3 grid(static_cast<unsigned>(rr_grid_for(biggest_split, 256, 64)), static_cast<unsigned>(n));
+    pack_split_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
+  }
   return rr_launch_status();
 }
 
 int64_t rr_packed_weight_ld(int k1, int k2) { return r16(k1) + r16(k2); }
+
+size_t rr_split_weight_bytes(int rows, int k1, int k2) {
+  if (rows < 1 || rows > 304 || k1 < 0 || k2 < 0 || k1 + k2 < 1) return 0;
+  return static_cast<size_t>((r32(k1) + r32(k2)) / SK) * split_nt(rows) * 3 * 1024;
+}
 
 int64_t rr_linear_colsum_rows(int64_t M) { return M <= 0 ? 0 : (M + BM - 1) / BM; }
 

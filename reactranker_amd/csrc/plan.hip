@@ -74,7 +74,7 @@ int stream_wait(hipStream_t waiter, hipStream_t signaller) {
 }
 
 // packed weight [rows, r16(k1)+r16(k2)] of W[:, c0 : c0+k1+k2] (transpose = 0) or of its transpose
-struct Packed { const float* w; int64_t ld; };
+struct Packed { const float* w; int64_t ld; int mode; };   // mode = rr_linear_args.w_packed (1 f32 layout, 2 bf16 terms)
 
 struct Ctx {
   bool launch;                        // false: layout pass only (no kernel is enqueued)
@@ -82,6 +82,7 @@ struct Ctx {
   Arena ar;
   Streams s;
   bool use_side, use_aux;
+  bool split;                         // encoder GEMMs on the bf16 matrix core (three exact bf16 terms per f32 operand)
   rr_pack_desc pq[RR_MAX_PACK];       // weight packs waiting for flush_packs()
   int npq;
   void fail(int st) { if (status == RR_OK && st != RR_OK) status = st; }
@@ -101,14 +102,25 @@ void flush_packs(Ctx& c, hipStream_t st) {
   c.npq = 0;
 }
 
-Packed pack(Ctx& c, const rr_linear_w& L, int transpose, int rows, int c0, int k1, int k2, hipStream_t st) {
+// big = the GEMM runs over atoms / bonds (the FFN head runs over molecules: a few thousand rows, launch-bound either way)
+Packed pack(Ctx& c, const rr_linear_w& L, int transpose, int rows, int c0, int k1, int k2, hipStream_t st, bool big = true) {
   Packed p;
-  p.ld = rr_packed_weight_ld(k1, k2);
-  float* dst = c.ar.f(rows, p.ld);
+  const bool split = c.split && big && rows <= 304 && rows % 4 == 0;
+  float* dst;
+  if (split) {
+    p.ld = 0;
+    p.mode = 2;
+    dst = c.ar.f(1, static_cast<int64_t>(rr_split_weight_bytes(rows, k1, k2) / 4));
+  } else {
+    p.ld = rr_packed_weight_ld(k1, k2);
+    p.mode = 1;
+    dst = c.ar.f(rows, p.ld);
+  }
   p.w = dst;
   if (c.npq == RR_MAX_PACK) flush_packs(c, st);
   rr_pack_desc& q = c.pq[c.npq++];
   q.src = L.w; q.ld_src = L.ldw; q.transpose = transpose; q.rows = rows; q.c0 = c0; q.k1 = k1; q.k2 = k2; q.dst = dst;
+  q.split = split ? 1 : 0;
   return p;
 }
 
@@ -124,7 +136,7 @@ rr_linear_args LA(int64_t M, int N) {
 
 // Packs are queued and issued together (rr_pack_weights_f32: one launch for up to 16 weights) by flush_packs().
 
-void set_w(rr_linear_args& a, const Packed& p) { a.w = p.w; a.ldw = p.ld; a.w_packed = 1; }
+void set_w(rr_linear_args& a, const Packed& p) { a.w = p.w; a.ldw = p.ld; a.w_packed = p.mode; }
 
 void gather_sum(Ctx& c, const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K, int H,
                 float* out, int64_t ld_out, hipStream_t st, const float* part = nullptr, int64_t n_part = 0, int64_t ld_part = 0) {
@@ -351,7 +363,7 @@ void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
   P.pk.dif_wi = pack(c, m.dif_wi, 0, H, 0, H, 0, main);
   if (m.diff_depth > 1) P.pk.dif_wh = pack(c, m.dif_wh, 0, H, 0, H, m.bond_fdim, main);
   if (m.diff_depth > 0) P.pk.dif_wo = pack(c, m.dif_wo, 0, H, 0, H, H, main);
-  for (int li = 0; li < m.n_ffn; ++li) P.pk.ffn[li] = pack(c, m.ffn[li], 0, m.ffn[li].out, 0, m.ffn[li].in, 0, main);
+  for (int li = 0; li < m.n_ffn; ++li) P.pk.ffn[li] = pack(c, m.ffn[li], 0, m.ffn[li].out, 0, m.ffn[li].in, 0, main, false);
   flush_packs(c, main);                                  // every forward weight in one launch
   hipStream_t rs = c.use_aux ? c.s.aux : main;
   if (c.launch && c.use_aux) c.fail(stream_wait(c.s.aux, main));
@@ -659,7 +671,7 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
   // every transposed weight of the backward in ONE pack launch
   PackedT T;
   memset(&T, 0, sizeof(T));
-  for (int li = 0; li < m.n_ffn; ++li) T.ffn[li] = pack(c, m.ffn[li], 1, ffn_dx_rows(m, li), 0, m.ffn[li].out, 0, main);
+  for (int li = 0; li < m.n_ffn; ++li) T.ffn[li] = pack(c, m.ffn[li], 1, ffn_dx_rows(m, li), 0, m.ffn[li].out, 0, main, false);
   if (m.diff_depth > 0) {
     T.dif_wo_x = pack(c, m.dif_wo, 1, H, 0, H, 0, main);
     T.dif_wo_a = pack(c, m.dif_wo, 1, H, H, H, 0, main);
@@ -736,16 +748,21 @@ void rr_abi_plan_struct_sizes(size_t* graph, size_t* model, size_t* step, size_t
 
 size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
   if (check(model, step) != RR_OK) return 0;
-  Ctx c;
-  c.launch = false; c.status = RR_OK; c.ar.base = nullptr; c.ar.off = 0; c.ar.cap = 0; c.ar.overflow = false; c.npq = 0;
-  c.use_side = c.use_aux = false;
-  Plan P;
-  memset(&P, 0, sizeof(P));
-  forward_all(c, *model, *step, P);
-  rr_grads G;
-  memset(&G, 0, sizeof(G));
-  backward_all(c, *model, *step, P, nullptr, G);
-  return c.ar.off + 256;
+  size_t need = 0;
+  for (int split = 0; split < 2; ++split) {            // either GEMM path (RR_PLAN_F32_GEMM) must fit
+    Ctx c;
+    c.launch = false; c.status = RR_OK; c.ar.base = nullptr; c.ar.off = 0; c.ar.cap = 0; c.ar.overflow = false; c.npq = 0;
+    c.use_side = c.use_aux = false;
+    c.split = split != 0;
+    Plan P;
+    memset(&P, 0, sizeof(P));
+    forward_all(c, *model, *step, P);
+    rr_grads G;
+    memset(&G, 0, sizeof(G));
+    backward_all(c, *model, *step, P, nullptr, G);
+    if (c.ar.off > need) need = c.ar.off;
+  }
+  return need + 256;
 }
 
 int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, rr_stream_t stream) {
@@ -757,6 +774,7 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.ar.base = static_cast<char*>(step->workspace); c.ar.off = 0; c.ar.cap = step->workspace_bytes; c.ar.overflow = false;
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
+  c.split = (flags & RR_PLAN_F32_GEMM) == 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   // the layout must fit BEFORE anything is launched (a dry pass costs microseconds)
@@ -789,6 +807,7 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.ar.base = static_cast<char*>(step->workspace); c.ar.off = 0; c.ar.cap = step->workspace_bytes; c.ar.overflow = false;
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
+  c.split = (flags & RR_PLAN_F32_GEMM) == 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   Plan P;

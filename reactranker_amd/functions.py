@@ -178,6 +178,8 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.a2, A.lda2, A.k2 = ptr(a2), _ld(a2), k2
     A.a_mask, A.ld_mask, A.mask_scale = ptr(a_mask), _ld(a_mask), float(mask_scale)
     A.dz_out, A.ld_dz, A.dz_accumulate = ptr(dz_out), _ld(dz_out), int(dz_accumulate)
+    if w.dtype == torch.uint8:                          # LinW.pk / pk_t handed out the three-bf16-term images
+        w_packed, ldw = 2, 0
     A.w, A.ldw, A.w_packed = ptr(w), (w.stride(0) if ldw is None else ldw), int(w_packed)
     A.bias = ptr(bias)
     A.residual, A.ldr, A.residual_idx = ptr(residual), _ld(residual), ptr(residual_idx)
@@ -192,7 +194,7 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
                   (1 + (residual is not None) + (c_pre is not None)))
     if dz_out is not None:                              # side output d_input (+)= dZ: one write, one read when accumulating
         nbytes += 4 * M * k1 * (2 if dz_accumulate else 1)
-    kern = "linear_fast_kernel" if w_packed else "linear_kernel"
+    kern = "linear_split_kernel" if int(w_packed) == 2 else ("linear_fast_kernel" if w_packed else "linear_kernel")
     with _Timed(f"{kern}<{nt},{mode}>", 2 * M * N * kk, nbytes):
         check(lib().rr_linear_f32(C.byref(A), stream()), "rr_linear_f32")
     return out if colsum_w is None else (out, partial)
@@ -353,34 +355,47 @@ def head_bwd(dout, raw, head: int):
 
 
 # =========================================================================== layer 2
-class LinW:
-    """One nn.Linear's tensors plus lazily transposed copies for the input-gradient GEMM."""
+class SplitGemm:
+    """Encoder GEMMs on the bf16 matrix core: every f32 operand is written exactly as three bf16 terms and six
+    products are accumulated in f32 (rr_linear_args.w_packed = 2; error at or below the f32 MFMA chain's).
+    enabled = False keeps every GEMM on v_mfma_f32_16x16x4_f32."""
+    enabled = True
 
-    def __init__(self, weight, bias):
+
+class LinW:
+    """One nn.Linear's tensors plus lazily transposed copies for the input-gradient GEMM.
+    big: its GEMMs run over atoms / bonds (the FFN head runs over molecules and stays on the f32 path)."""
+
+    def __init__(self, weight, bias, big: bool = True):
         self.w = None if weight is None else _rowmajor(weight.detach(), "weight")
         self.b = None if bias is None else _rowmajor(bias.detach(), "bias")
+        self.big = big
         self._t = {}
 
+    def _pack(self, transpose: int, rows: int, c0: int, k1: int, k2: int):
+        split = SplitGemm.enabled and self.big and rows <= 304 and rows % 4 == 0
+        d = (_lib.PackDesc * 1)()
+        if split:
+            dst = torch.empty(int(lib().rr_split_weight_bytes(rows, k1, k2)), dtype=torch.uint8, device=self.w.device)
+        else:
+            dst = torch.empty(rows, int(lib().rr_packed_weight_ld(k1, k2)), dtype=torch.float32, device=self.w.device)
+        d[0].src, d[0].ld_src, d[0].transpose, d[0].rows, d[0].c0, d[0].k1, d[0].k2 = ptr(self.w), self.w.stride(0), transpose, rows, c0, k1, k2
+        d[0].dst, d[0].split = ptr(dst), int(split)
+        check(lib().rr_pack_weights_f32(d, 1, stream()), "rr_pack_weights_f32")
+        return dst
+
     def pk(self, k1: int, k2: int = 0):
-        """Zero-padded packed copy of W = [W1 | W2] (rr_pack_weight_f32) for the fast GEMM path."""
-        key = ("f", k1, k2)
+        """Packed copy of W = [W1 | W2] for the fast GEMM paths (rr_pack_weights_f32: zero-padded f32, or bf16 terms)."""
+        key = ("f", k1, k2, SplitGemm.enabled)
         if key not in self._t:
-            n = self.w.shape[0]
-            dst = torch.empty(n, int(lib().rr_packed_weight_ld(k1, k2)), dtype=torch.float32, device=self.w.device)
-            check(lib().rr_pack_weight_f32(ptr(self.w), self.w.stride(0), 0, n, 0, k1, k2, ptr(dst), stream()),
-                  "rr_pack_weight_f32")
-            self._t[key] = dst
+            self._t[key] = self._pack(0, self.w.shape[0], 0, k1, k2)
         return self._t[key]
 
     def pk_t(self, c0: int, c1: int):
         """Packed (W[:, c0:c1])^T — the weight operand of dX = dZ * W[:, c0:c1]."""
-        key = ("t", c0, c1)
+        key = ("t", c0, c1, SplitGemm.enabled)
         if key not in self._t:
-            n = self.w.shape[0]
-            dst = torch.empty(c1 - c0, int(lib().rr_packed_weight_ld(n, 0)), dtype=torch.float32, device=self.w.device)
-            check(lib().rr_pack_weight_f32(ptr(self.w), self.w.stride(0), 1, c1 - c0, c0, n, 0, ptr(dst), stream()),
-                  "rr_pack_weight_f32")
-            self._t[key] = dst
+            self._t[key] = self._pack(1, c1 - c0, c0, self.w.shape[0], 0)
         return self._t[key]
 
     def grads(self):
@@ -862,7 +877,8 @@ class StepPlan:
 
     @staticmethod
     def flags() -> int:
-        return (0 if SideStream.enabled else _lib.RR_PLAN_NO_SIDE_STREAM) | (0 if AuxStream.enabled else _lib.RR_PLAN_NO_AUX_STREAM)
+        return ((0 if SideStream.enabled else _lib.RR_PLAN_NO_SIDE_STREAM) | (0 if AuxStream.enabled else _lib.RR_PLAN_NO_AUX_STREAM) |
+                (0 if SplitGemm.enabled else _lib.RR_PLAN_F32_GEMM))
 
 
 class ReactionModelFn(torch.autograd.Function):
@@ -882,8 +898,9 @@ class ReactionModelFn(torch.autograd.Function):
                 raise RuntimeError("rr_reaction_workspace_bytes rejected the step (inconsistent model / batch shapes)")
             ws = torch.empty(nbytes, dtype=torch.uint8, device=pg.device)
             S.workspace, S.workspace_bytes = C.c_void_p(ws.data_ptr()), nbytes
-            check(lib().rr_reaction_forward(C.byref(M), C.byref(S), StepPlan.flags(), stream()), "rr_reaction_forward")
-            ctx.plan = (M, S, keep, ws, out)
+            flags = StepPlan.flags()                    # the backward must lay the workspace out the same way
+            check(lib().rr_reaction_forward(C.byref(M), C.byref(S), flags, stream()), "rr_reaction_forward")
+            ctx.plan = (M, S, keep, ws, out, flags)
             ctx.st = st
             ctx.param_shapes = [None if q is None else q for q in params]
             ctx.present = [q is not None for q in params]
@@ -892,7 +909,7 @@ class ReactionModelFn(torch.autograd.Function):
                LinW(params[4], params[5])]
         dif = [LinW(params[6], params[7]), LinW(params[8], params[9]) if params[8] is not None else None,
                LinW(params[10], params[11]) if params[10] is not None else None]
-        ffn = [LinW(params[i], params[i + 1]) for i in range(12, len(params), 2)]
+        ffn = [LinW(params[i], params[i + 1], big=False) for i in range(12, len(params), 2)]
         H, p, seed = st["H"], st["p"], st["seed"]
         rg, pg = st["r"], st["p_graph"]
         dev = rg.device
@@ -938,7 +955,7 @@ class ReactionModelFn(torch.autograd.Function):
             if ctx.plan == "done":
                 raise RuntimeError("ReactionModelFn: backward ran twice; the saved activations are released after the "
                                    "first backward (retain_graph=True is not supported by the explicit backward)")
-            M, S, keep, ws, out = ctx.plan
+            M, S, keep, ws, out, flags = ctx.plan
             dout = _rowmajor(dout.reshape(out.shape), "grad_output")
             G = _lib.Grads()
             grads = []
@@ -949,7 +966,7 @@ class ReactionModelFn(torch.autograd.Function):
                 gb = None if b is None else torch.empty_like(b)
                 G.w[gi], G.b[gi] = ptr(gw), ptr(gb)
                 grads += [gw, gb]
-            check(lib().rr_reaction_backward(C.byref(M), C.byref(S), ptr(dout), C.byref(G), StepPlan.flags(), stream()),
+            check(lib().rr_reaction_backward(C.byref(M), C.byref(S), ptr(dout), C.byref(G), flags, stream()),
                   "rr_reaction_backward")
             ctx.plan = "done"
             return (None, *grads)
@@ -1053,7 +1070,7 @@ class FFNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, st, x, *params):
-        layers = [LinW(params[i], params[i + 1]) for i in range(0, len(params), 2)]
+        layers = [LinW(params[i], params[i + 1], big=False) for i in range(0, len(params), 2)]
         xx = _rowmajor(x.detach(), "ffn input")
         p = st["p"]
         xin = dropout(xx, p, _site_seed(st["seed"], 9)) if p > 0 else xx
