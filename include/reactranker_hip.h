@@ -207,6 +207,9 @@ typedef struct rr_wgrad_args {
   float* dbias;                                     /* [N] or NULL */
   int accumulate;                                   /* 0: overwrite, 1: add into dw/dbias */
   void* workspace;       size_t workspace_bytes;
+  int split;                                        /* 1: three-bf16-term operands on the bf16 matrix core (f32-equivalent
+                                                       accuracy, see rr_pack_desc.split) where the geometry allows vector
+                                                       loads (16-byte aligned rows, N % 4 == 0); the f32 path otherwise */
 } rr_wgrad_args;
 
 size_t rr_linear_wgrad_workspace_bytes(int64_t M, int N, int K);

@@ -59,6 +59,7 @@ class WgradArgs(C.Structure):
         ("dbias", c_f32p),
         ("accumulate", i32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("split", i32),
     ]
 
 

@@ -1412,6 +1412,254 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_fast_kernel(const WgradParam
 #endif
 }
 
+// ------------------------------------------------------------------------ weight gradient, split path
+// dW = dZ^T X on the bf16 matrix core with the three-term operand split of linear_split_kernel: here BOTH operands are
+// activations, so each staged element is split once per workgroup when it is written to LDS (row-major bf16 term
+// images [term][32 rows of M][columns]), and the MFMA operands - 8 consecutive rows of M for one column - come out of
+// ds_read_b64_tr_b16, the transposing LDS read (a 16-lane group reads 4 rows x 16 columns and each lane receives one
+// column).  Output tile, M-chunking, slab layout and the fixed-order reduction are those of wgrad_fast_kernel.
+// Loader: thread t owns row t/8 of the 32-row tile and the 16-byte chunks (t%8) + 8 i of that row: one row pointer
+// per operand, one gather index per tile.  One LDS stage of 60 KB (two workgroups per CU overlap each other's
+// staging with MFMA); image rows are 64 (mod 128) bytes apart so the 8-byte term stores are conflict-free, and the
+// 32-byte column blocks of rows 8-15 / 24-31 are swapped pairwise (XOR 32) so that the two row quads a 32-lane half
+// reads in one transposed read (rows r..r+3 and r+8..r+11) fall on different banks.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* rr_lds_s16x4;
+
+__device__ __forceinline__ u32x4 tr_read8(const unsigned char* p, int rowbytes) {     // rows r..r+3 and r+4..r+7
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rr_lds_s16x4)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rr_lds_s16x4)(p + 4 * rowbytes));
+  u32x4 r;
+  r.x = __builtin_bit_cast(uint2, lo).x; r.y = __builtin_bit_cast(uint2, lo).y;
+  r.z = __builtin_bit_cast(uint2, hi).x; r.w = __builtin_bit_cast(uint2, hi).y;
+  return r;
+}
+
+constexpr int SMT = 32;             // rows of M per staged tile on the split path
+
+template <bool HAS_MASK, bool HAS_SUB, int WTK>
+__global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradParams P) {
+  constexpr int KB = 32 * WTK;                          // columns per k-block (160 / 128 / 96)
+  constexpr int ZRB = 320;                              // bytes per row of a dZ term image (160 bf16)
+  constexpr int XRB = WTK == 3 ? 192 : 320;             // X term image (WTK 4: 256 bytes of data + 64 of pad)
+  constexpr int ZIMG = SMT * ZRB, XIMG = SMT * XRB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * ZIMG + 3 * XIMG];
+  const rr_wgrad_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = P.nblk_n * P.nblk_k;                   // XCD-aware mapping, see wgrad_fast_kernel
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = slot % nt, chunk = (slot / nt) * 8 + xcd;
+  if (chunk >= P.nchunks) return;
+  const int bn = tile / P.nblk_k, bk = tile % P.nblk_k;
+  const int nb = bn * WBN, kb = bk * KB;
+  const int64_t mbeg = static_cast<int64_t>(chunk) * P.rows_per_chunk;
+  int64_t mend = mbeg + P.rows_per_chunk;
+  if (mend > a.M) mend = a.M;
+  const int K = a.k1 + a.k2;
+  const int nrows = static_cast<int>(mend - mbeg);
+  const int ntiles = (nrows + SMT - 1) / SMT;
+  const float* const zero = rr_zero_chunk;
+
+  // ---- loader role: row r of the tile, chunks g + 8 i
+  const int r = tid >> 3, g = tid & 7;
+  const int xr = ((r >> 3) & 1) << 5;                   // column-block swap of this row in the images
+  enum : int { X_NONE = 0, X_SEG1 = 1, X_SEG2 = 2, X_ONES = 3 };
+  bool zok[5];
+  int xcode[WTK];                                       // per chunk: column | kind << 16 | valid elements << 18 | (ones element + 1) << 21
+  bool partial = false;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) zok[i] = nb + 4 * (g + 8 * i) < a.N;
+#pragma unroll
+  for (int i = 0; i < WTK; ++i) {
+    const int kx = kb + 4 * (g + 8 * i);                // extended column of the chunk
+    int kind = X_NONE, col = 0, nv = 4, one = -1;
+    if (kx < a.k1) {
+      kind = X_SEG1; col = kx; nv = min(4, a.k1 - kx);
+    } else if (kx >= P.k1p && kx < P.kext) {
+      const int c2 = kx - P.k1p;
+      if (c2 < a.k2) {
+        kind = X_SEG2; col = c2; nv = min(4, a.k2 - c2);
+        if (a.k2 - c2 < 4) one = a.k2 - c2;             // the ones column shares this chunk (k2 % 4 != 0)
+      } else {
+        kind = X_ONES; nv = 0; one = 0;                 // c2 == k2: the chunk is {1, 0, 0, 0}
+      }
+    }
+    if (nv != 4 || one >= 0) partial = true;
+    xcode[i] = col | (kind << 16) | (nv << 18) | ((one + 1) << 21);
+  }
+  partial = __any(partial);
+
+  f32x4 zv[5], zm[5], xv[WTK], xs[WTK];
+  bool m_ok = false;                                    // this thread's row of the tile in flight is inside the M-chunk
+  int32_t ia = 0, is = 0;                               // gather indices of the NEXT tile's row
+  auto fetch_idx = [&](int t) {                         // rows past the chunk read the last row's index (never used)
+    int rr = t * SMT + r;
+    if (rr > nrows - 1) rr = nrows - 1;
+    ia = a.x1_idx ? ldgi(a.x1_idx + mbeg + rr) : 0;
+    if (HAS_SUB) is = a.x1_sub_idx ? ldgi(a.x1_sub_idx + mbeg + rr) : 0;
+  };
+  auto issue = [&](int t) {                             // every load is issued; the address is what gets selected
+    const int rr = t * SMT + r;
+    m_ok = rr < nrows;
+    const int64_t m = mbeg + (m_ok ? rr : 0);
+    const float* zp = a.dy + m * a.ld_dy + nb + 4 * g;
+    const float* mp = HAS_MASK ? a.mask + m * a.ld_mask + nb + 4 * g : zero;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      zv[i] = ldg4((m_ok && zok[i]) ? zp + 32 * i : zero);
+      if (HAS_MASK) zm[i] = ldg4((m_ok && zok[i]) ? mp + 32 * i : zero);
+    }
+    const float* p1 = nullptr;
+    const float* ps = nullptr;
+    if (a.k1 > 0) {
+      if (a.x1_idx) {
+        if (ia >= 0) p1 = a.x1 + static_cast<int64_t>(ia) * a.ldx1;
+      } else {
+        p1 = a.x1 + m * a.ldx1;
+      }
+      if (HAS_SUB) {
+        if (a.x1_sub_idx) {
+          if (is >= 0) ps = a.x1_sub + static_cast<int64_t>(is) * a.ldx1_sub;
+        } else {
+          ps = a.x1_sub + m * a.ldx1_sub;
+        }
+      }
+    }
+    const float* p2 = a.k2 > 0 ? a.x2 + m * a.ldx2 : nullptr;
+#pragma unroll
+    for (int i = 0; i < WTK; ++i) {
+      const int kind = (xcode[i] >> 16) & 3, col = xcode[i] & 0xffff;
+      const float* src = kind == X_SEG1 ? p1 : (kind == X_SEG2 ? p2 : nullptr);
+      xv[i] = ldg4((m_ok && src != nullptr) ? src + col : zero);
+      if (HAS_SUB) xs[i] = ldg4((m_ok && ps != nullptr && kind == X_SEG1) ? ps + col : zero);
+    }
+  };
+  auto put = [&](unsigned char* img, int imgbytes, int rowbytes, int chunk8, f32x4 v) {   // split + three 8-byte stores
+    uint32_t a0, a1, a2, b0, b1, b2;
+    split_pair(v.x, v.y, a0, a1, a2);
+    split_pair(v.z, v.w, b0, b1, b2);
+    unsigned char* d = img + r * rowbytes + ((chunk8 * 8) ^ xr);
+    *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+    *reinterpret_cast<uint2*>(d + imgbytes) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(d + 2 * imgbytes) = make_uint2(a2, b2);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      f32x4 z = zv[i];
+      if (HAS_MASK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = zm[i][e] > 0.f ? zv[i][e] * a.mask_scale : 0.f;
+      }
+      put(lds, ZIMG, ZRB, g + 8 * i, z);
+    }
+#pragma unroll
+    for (int i = 0; i < WTK; ++i) {
+      f32x4 x = xv[i];
+      if (HAS_SUB) x = xv[i] - xs[i];
+      if (partial) {                                    // k1 % 4 or k2 % 4 != 0, or the ones column: patch per element
+        const int nv = (xcode[i] >> 18) & 7, one = ((xcode[i] >> 21) & 7) - 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = e < nv ? xv[i][e] : 0.f;
+          if (HAS_SUB) u -= e < nv ? xs[i][e] : 0.f;
+          if (e == one) u = m_ok ? 1.0f : 0.f;
+          x[e] = u;
+        }
+      }
+      put(lds + 3 * ZIMG, XIMG, XRB, g + 8 * i, x);
+    }
+  };
+
+  f32x4 acc[WT][WTK];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WTK; ++j) acc[i][j] = f32x4(0.f);
+
+  const int wn = (wave >> 1) * (WT * 16), wk = (wave & 1) * (WTK * 16);
+  const int fr = lane & 15, fq = lane >> 4;
+  // transposed-read role: lane 4q+p of 16-lane group fq supplies row 8 fq + q, columns 4p..4p+3 of the 16-column block
+  const int tq = fr >> 2, tp = fr & 3;
+  const int trow = 8 * fq + tq;
+  const int txr = (fq & 1) << 5;
+  const unsigned char* const zbase = lds + trow * ZRB + 8 * tp;
+  const unsigned char* const xbase = lds + 3 * ZIMG + trow * XRB + 8 * tp;
+
+  fetch_idx(0);
+  issue(0);
+  fetch_idx(1);
+  for (int t = 0; t < ntiles; ++t) {
+    commit();                                           // waits for the tile's loads; splits; writes the term images
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      issue(t + 1);
+      fetch_idx(t + 2);
+    }
+    // The X terms of a group of k-tiles stay in registers across the five n-tiles (36 / 24 registers); holding all
+    // WTK at once (what common-subexpression elimination makes of the plain double loop) spills next to the 100
+    // accumulators and the next tile's chunks in flight.
+    constexpr int JH = WTK <= 3 ? WTK : 3;
+#pragma unroll
+    for (int j0 = 0; j0 < WTK; j0 += JH) {
+      asm volatile("" ::: "memory");                    // the second group RE-READS the dZ terms (no CSE across groups)
+      bf16x8 b0[JH], b1[JH], b2[JH];
+#pragma unroll
+      for (int jj = 0; jj < JH; ++jj) {
+        if (j0 + jj < WTK) {
+          const int xc = ((wk + 16 * (j0 + jj)) * 2) ^ txr;
+          b0[jj] = as_bf16x8(tr_read8(xbase + xc, XRB));
+          b1[jj] = as_bf16x8(tr_read8(xbase + XIMG + xc, XRB));
+          b2[jj] = as_bf16x8(tr_read8(xbase + 2 * XIMG + xc, XRB));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        const int zc = ((wn + 16 * i) * 2) ^ txr;
+        const bf16x8 a0 = as_bf16x8(tr_read8(zbase + zc, ZRB));
+        const bf16x8 a1 = as_bf16x8(tr_read8(zbase + ZIMG + zc, ZRB));
+        const bf16x8 a2 = as_bf16x8(tr_read8(zbase + 2 * ZIMG + zc, ZRB));
+#pragma unroll
+        for (int jj = 0; jj < JH; ++jj) {
+          if (j0 + jj < WTK) {
+            f32x4 c = acc[i][j0 + jj];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0[jj], c, 0, 0, 0);   // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[jj], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2[jj], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0[jj], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1[jj], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[jj], c, 0, 0, 0);
+            acc[i][j0 + jj] = c;
+          }
+        }
+      }
+    }
+    __syncthreads();                                    // every wave is done with the images before the next commit
+  }
+
+  float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(chunk) * P.slab;
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+#pragma unroll
+    for (int j = 0; j < WTK; ++j) {
+      const int kx = kb + wk + j * 16 + fr;
+      if (kx >= P.kext) continue;
+      int kreal = -1;
+      if (kx < a.k1) kreal = kx;
+      else if (kx >= P.k1p && kx < P.k1p + a.k2) kreal = a.k1 + (kx - P.k1p);
+      else if (kx == P.k1p + a.k2) kreal = -2;
+      if (kreal == -1) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = nb + wn + i * 16 + fq * 4 + e;
+        if (n >= a.N) continue;
+        if (kreal >= 0) slab[static_cast<int64_t>(n) * K + kreal] = acc[i][j][e];
+        else slab[static_cast<int64_t>(a.N) * K + n] = acc[i][j][e];
+      }
+    }
+  }
+}
+
 // fixed-order sum of the chunk slabs into dw / dbias
 __global__ void __launch_bounds__(THREADS) wgrad_reduce_kernel(const float* __restrict__ ws, int nchunks, int64_t slab,
                                                                int N, int K, float* __restrict__ dw, int64_t ld_dw,
@@ -1457,15 +1705,15 @@ int64_t wgrad_want_chunks(int64_t M, int N, int kext) {
   return want;
 }
 
-void wgrad_plan(int64_t M, int N, int k1, int k2, WgradParams* P) {
+void wgrad_plan(int64_t M, int N, int k1, int k2, WgradParams* P, int mt = WMT) {
   P->k1p = (k1 + 3) & ~3;                         // segment 2 (and the ones column) start 16-byte aligned
   P->kext = P->k1p + k2 + 1;
   P->nblk_n = (N + WBN - 1) / WBN;
   P->nblk_k = (P->kext + WBN - 1) / WBN;
   const int64_t want = wgrad_want_chunks(M, N, P->kext);
   int64_t rpc = (M + want - 1) / want;
-  rpc = (rpc + WMT - 1) / WMT * WMT;
-  if (rpc < WMT) rpc = WMT;
+  rpc = (rpc + mt - 1) / mt * mt;
+  if (rpc < mt) rpc = mt;
   P->rows_per_chunk = rpc;
   P->nchunks = static_cast<int>((M + rpc - 1) / rpc);
   if (P->nchunks < 1) P->nchunks = 1;
@@ -1655,7 +1903,8 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
   const int K = a.k1 + a.k2;
   WgradParams P;
   P.a = a;
-  wgrad_plan(a.M, a.N, a.k1, a.k2, &P);
+  RR_CHECK_ARG(a.split == 0 || a.split == 1);
+  wgrad_plan(a.M, a.N, a.k1, a.k2, &P, a.split ? SMT : WMT);
   if (a.workspace_bytes < static_cast<size_t>(P.nchunks) * static_cast<size_t>(P.slab) * sizeof(float))
     return RR_ERR_WORKSPACE;
   P.flags = 0;
@@ -1678,6 +1927,19 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
     // narrowest k-block (96 / 128 / 160 columns) that still covers kext with nblk_k blocks
     const int per_blk = (P.kext + P.nblk_k - 1) / P.nblk_k;
     const int wtk = per_blk <= 96 ? 3 : (per_blk <= 128 ? 4 : 5);
+    if (a.split) {                                      // (a request: the scalar-load geometry below stays on f32)
+#define RR_WSPLIT_LAUNCH(MASK, SUB)                                                        \
+    do {                                                                                   \
+      if (wtk == 3) wgrad_split_kernel<MASK, SUB, 3><<<grid, THREADS, 0, s>>>(P);          \
+      else if (wtk == 4) wgrad_split_kernel<MASK, SUB, 4><<<grid, THREADS, 0, s>>>(P);     \
+      else wgrad_split_kernel<MASK, SUB, 5><<<grid, THREADS, 0, s>>>(P);                   \
+    } while (0)
+      if (a.mask && a.x1_sub) RR_WSPLIT_LAUNCH(true, true);
+      else if (a.mask) RR_WSPLIT_LAUNCH(true, false);
+      else if (a.x1_sub) RR_WSPLIT_LAUNCH(false, true);
+      else RR_WSPLIT_LAUNCH(false, false);
+#undef RR_WSPLIT_LAUNCH
+    } else {
 #define RR_WGRAD_LAUNCH(MASK, SUB)                                                         \
     do {                                                                                   \
       if (wtk == 3) wgrad_fast_kernel<MASK, SUB, 3><<<grid, THREADS, 0, s>>>(P);           \
@@ -1689,6 +1951,7 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
     else if (a.x1_sub) RR_WGRAD_LAUNCH(false, true);
     else RR_WGRAD_LAUNCH(false, false);
 #undef RR_WGRAD_LAUNCH
+    }
   } else {
     wgrad_kernel<<<grid, THREADS, 0, s>>>(P);
   }

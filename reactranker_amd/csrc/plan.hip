@@ -149,6 +149,7 @@ void wgrad(Ctx& c, rr_wgrad_args& a) {
   const size_t wb = rr_linear_wgrad_workspace_bytes(a.M, a.N, a.k1 + a.k2);
   a.workspace = c.ar.f(1, static_cast<int64_t>((wb + 3) / 4));
   a.workspace_bytes = wb;
+  a.split = (c.split && a.M >= 8192) ? 1 : 0;           // the FFN head (one row per molecule) stays on the f32 matrix core
   if (!c.launch || c.status != RR_OK) return;
   hipStream_t st = c.use_side ? c.s.side : c.s.main;
   if (c.use_side) c.fail(stream_wait(c.s.side, c.s.main));

@@ -239,6 +239,9 @@ class AuxStream:
         return cls._streams[key]
 
 
+SPLIT_MIN_ROWS = 8192      # GEMMs over fewer rows (the FFN head: one row per molecule) stay on the f32 matrix core
+
+
 def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=None, k1=0, x1_idx=None, x1_sub=None,
           x1_sub_idx=None, x2=None, k2=0, accumulate=False, ld_dw=None, side=False):
     """dw (+)= dZ^T [X1|X2], dbias (+)= colsum(dZ) with dZ = dy * (mask > 0) * mask_scale.
@@ -274,12 +277,14 @@ def _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub,
     A.dbias = ptr(dbias)
     A.accumulate = int(accumulate)
     A.workspace, A.workspace_bytes = ptr(ws), nbytes
+    A.split = int(SplitGemm.enabled and M >= SPLIT_MIN_ROWS and N % 4 == 0 and
+                  all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in (dy, mask, x1, x1_sub, x2)))
     # the event pair spans the main kernel and its ~12 us fixed-order reduce kernel
     kext = ((k1 + 3) & ~3) + k2 + 1                     # same k-block choice as rr_linear_wgrad_f32 (96 / 128 / 160 columns)
     nblk = (kext + 159) // 160
     per = (kext + nblk - 1) // nblk
     wtk = 3 if per <= 96 else (4 if per <= 128 else 5)
-    key = (f"wgrad_fast_kernel<{'true' if mask is not None else 'false'},"
+    key = (f"{'wgrad_split_kernel' if A.split else 'wgrad_fast_kernel'}<{'true' if mask is not None else 'false'},"
            f"{'true' if x1_sub is not None else 'false'},{wtk}>")
     with _Timed(key, 2 * M * N * (K + 1), 4 * (M * N * (2 if mask is not None else 1) + M * K + N * K)):
         check(lib().rr_linear_wgrad_f32(C.byref(A), stream()), "rr_linear_wgrad_f32")
