@@ -417,7 +417,8 @@ enum { RR_STEP_PLAIN = 0,    /* encoder(r) on the full reactant batch */
        RR_STEP_DEDUP = 1,    /* dropout inactive: `r` holds the DISTINCT reactants, amap / amap_t map product atoms to them */
        RR_STEP_PREFIX = 2 }; /* train mode: `u` holds the distinct reactants, only the deterministic prefix is shared */
 enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2,
-       RR_PLAN_F32_GEMM = 4 };   /* encoder GEMMs on the f32 matrix core instead of the three-bf16-term path (w_packed = 2);
+       RR_PLAN_F32_GEMM = 4,
+       RR_PLAN_AUX_BACKWARD = 8 };   /* reactant-encoder backward on the aux stream beside the product pass */   /* encoder GEMMs on the f32 matrix core instead of the three-bf16-term path (w_packed = 2);
                                     forward and backward of a step must agree on it (it changes the workspace layout) */
 
 typedef struct rr_step {

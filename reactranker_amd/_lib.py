@@ -66,7 +66,7 @@ class WgradArgs(C.Structure):
 RR_MAX_FFN = 8
 RR_G_FFN0 = 6
 RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
-RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM = 1, 2, 4
+RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM, RR_PLAN_AUX_BACKWARD = 1, 2, 4, 8
 
 
 class Graph(C.Structure):

@@ -636,12 +636,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SK = 32;                    // k per step
-#ifndef RR_SPLIT_WAVES
-#define RR_SPLIT_WAVES 12
-#endif
-constexpr int S_WAVES = RR_SPLIT_WAVES;       // 12 waves = 3 per SIMD (<= 168 registers), 192 rows per workgroup
-constexpr int S_THREADS = 64 * S_WAVES;
-constexpr int S_BM = 16 * S_WAVES;
 
 __host__ __device__ constexpr int r32(int k) { return (k + 31) & ~31; }
 
@@ -661,12 +655,23 @@ __device__ __forceinline__ void split_pair(float x, float y, uint32_t& p0, uint3
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int NT, int MODE>
-__global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearParams P) {
+// NTP: column tiles of the packed weight image; NT: column tiles of ONE workgroup (blockIdx.y picks tiles y * NT ...);
+// WAVES: 16-row groups per workgroup.  Instantiated: <19, 19, 12 waves> - one workgroup per CU (114 KB of LDS) covers all
+// columns of 192 rows - and <10, 10, 8> / <4, 4, 8> for narrow layers.  Cutting the 19 tiles into 10 + 9 (<19, 10, 8>:
+// 60 KB, <= 128 registers, TWO workgroups per CU whose store epilogues and MFMA loops overlap) was measured and lost:
+// both halves load and split the operand rows, 320 vs 236 us on the masked dX GEMM (profiles/r02_experiments.txt).
+template <int NTP, int NT, int MODE, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_kernel(const LinearParams P) {
   constexpr int BN = 16 * NT;
-  constexpr int PANEL = NT * 3 * 1024;                 // bytes of one k-step's weight image
+  constexpr int PANEL = NT * 3 * 1024;                 // bytes of one k-step's weight image in LDS
+  constexpr int SRC_PANEL = NTP * 3 * 1024;            // ... and in the packed weights
+  constexpr int S_BM = 16 * WAVES, S_THREADS = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const bias_s = reinterpret_cast<float*>(smem + 2 * PANEL);
+  const int t0 = blockIdx.y * NT;                      // first column tile of this workgroup
+  const int nth = NTP - t0 < NT ? NTP - t0 : NT;       // its column tiles (the last workgroup of a row block may have fewer)
+  const bool full = nth == NT;
+  const int n0 = t0 * 16;
 
   const rr_linear_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -704,10 +709,10 @@ __global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearPar
     }
   }
   float* dzrow = nullptr;                              // MODE 2 side output: dz_out (+)= masked operand
-  if (MODE == 2 && a.dz_out && row_ok) dzrow = a.dz_out + m * a.ld_dz;
+  if (MODE == 2 && a.dz_out && row_ok && blockIdx.y == 0) dzrow = a.dz_out + m * a.ld_dz;
 
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
-  const float* const wlane = a.w + lane * 4;           // 16 B per lane inside a 1 KiB block
+  const float* const wlane = a.w + t0 * 768 + lane * 4;   // this workgroup's tiles of a step; 16 B per lane inside a 1 KiB block
   const uint32_t lds0 = rr_lds_addr(reinterpret_cast<const float*>(smem));
 
   f32x4 acc[NT];
@@ -716,7 +721,7 @@ __global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearPar
 
   const int nk = P.t1 + P.t2;
   // operand chunks in flight: two k-steps (slot = step & 1), so a load has two MFMA blocks to land; the weight image one
-  f32x4 ra[2][2], rs[2][2];
+  f32x4 ra[NT == NTP ? 2 : 1][2], rs[NT == NTP ? 2 : 1][2];
   u32x4 x0, x1, x2;                                    // the three bf16 terms of the current step's operand
 
   auto issue_x = [&](int s, int slot) {                // pure loads (unconditional, from a selected address)
@@ -733,12 +738,12 @@ __global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearPar
     }
   };
   auto issue_w = [&](int s) {                          // weight image of step s: NT * 3 LDS-DMA blocks of 1 KiB over the waves
-    const float* src = wlane + static_cast<int64_t>(s) * (PANEL / 4);
+    const float* src = wlane + static_cast<int64_t>(s) * (SRC_PANEL / 4);
     const uint32_t dst = lds0 + (s & 1) * PANEL;
 #pragma unroll
-    for (int b0 = 0; b0 < NT * 3; b0 += S_WAVES) {
+    for (int b0 = 0; b0 < NT * 3; b0 += WAVES) {
       const int b = b0 + uwave;
-      if (b < NT * 3) rr_glds16(src + b * 256, dst + b * 1024);
+      if (b < nth * 3) rr_glds16(src + b * 256, dst + b * 1024);
     }
   };
   auto fixup = [&](int s, int slot) {                  // first use of the loads: selects, mask / subtract, split
@@ -797,6 +802,7 @@ __global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearPar
         wc = Ws[((j + 1) * 3 + 2) * 64];
       }
       f32x4 c = acc[j];
+      if (j + 1 == NT && NT != NTP && !full) continue;  // (uniform) the narrower last column block has no tile NT-1
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, b0, c, 0, 0, 0);   // smallest terms first
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, b1, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, b2, c, 0, 0, 0);
@@ -811,28 +817,33 @@ __global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearPar
   // one k-step with compile-time slots.  vmcnt retires in issue order: the operand loads of step s+2 are issued AFTER the
   // weight image of step s+1, so "all but the youngest NX" = image landed, step s+1's chunks landed, step s+2's in flight.
   constexpr int NX = MODE == 0 ? 2 : 4;                // vector-memory instructions of one issue_x
+  constexpr bool DEEP = NT == NTP;                     // the two-workgroups-per-CU geometry has 128 registers: one step ahead
   auto step = [&](int s, int slot) {
     const bool more = s + 1 < nk, more2 = s + 2 < nk;
     if (more) issue_w(s + 1);
-    if (more2) issue_x(s + 2, slot);
+    if (DEEP) {
+      if (more2) issue_x(s + 2, slot);
+    } else {
+      if (more) issue_x(s + 1, 0);
+    }
     mfma_block(s);
-    if (more2) {
+    if (DEEP && more2) {
       if (NX == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       rr_wait_vm0();
     }
-    if (more) fixup(s + 1, slot ^ 1);
+    if (more) fixup(s + 1, DEEP ? slot ^ 1 : 0);
     __syncthreads();
   };
 
   if (tid < BN / 4) {
-    const int n = tid * 4;
+    const int n = n0 + tid * 4;
     *reinterpret_cast<f32x4*>(bias_s + tid * 4) = ldg4((a.bias && n < a.N) ? a.bias + n : dummy);
   }
   issue_w(0);
   issue_x(0, 0);
-  if (nk > 1) issue_x(1, 1);
+  if (DEEP && nk > 1) issue_x(1, 1);
   rr_wait_vm0();
   fixup(0, 0);
   __syncthreads();
@@ -876,7 +887,7 @@ __global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearPar
     constexpr int D = 4;
     f32x4 ring[D + 1];
     auto ldres = [&](int tc) {
-      const int n = tc * 16 + nq;
+      const int n = n0 + tc * 16 + nq;
       return ldg4(rbase + ((res_ok && n < a.N) ? n : 0));
     };
 #pragma unroll
@@ -884,7 +895,7 @@ __global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearPar
       if (t < NT) ring[t] = ldres(t);
 #pragma unroll
     for (int tc = 0; tc < NT; ++tc) {
-      const int n = tc * 16 + nq;
+      const int n = n0 + tc * 16 + nq;
       const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + tc * 16 + nq);
       f32x4 v = acc[tc];
       const f32x4 vb = v + b;
@@ -913,16 +924,16 @@ __global__ void __launch_bounds__(S_THREADS) linear_split_kernel(const LinearPar
   }
   if (cs_on) {                                         // one partial row per 64 rows (rr_linear_colsum_rows) = per 4 waves
     __syncthreads();
-    static_assert(S_WAVES % 4 == 0 && (S_WAVES / 4) * (BN / 4) <= S_THREADS, "colsum slices");
-    if (tid < (S_WAVES / 4) * (BN / 4)) {
+    static_assert(WAVES % 4 == 0 && (WAVES / 4) * (BN / 4) <= S_THREADS, "colsum slices");
+    if (tid < (WAVES / 4) * (BN / 4)) {
       const int h = tid / (BN / 4);
       const int q = tid - h * (BN / 4);
-      const int n = q * 4;
+      const int n = n0 + q * 4;
       const float* base = cs_lds + h * 4 * BN + q * 4;
       const f32x4 s01 = ld4(base) + ld4(base + BN);
       const f32x4 s23 = ld4(base + 2 * BN) + ld4(base + 3 * BN);
       if (n < a.N && m0 + h * 64 < a.M)
-        *reinterpret_cast<f32x4*>(a.colsum_partial + (static_cast<int64_t>(blockIdx.x) * (S_WAVES / 4) + h) * a.ld_partial + n) = s01 + s23;
+        *reinterpret_cast<f32x4*>(a.colsum_partial + (static_cast<int64_t>(blockIdx.x) * (WAVES / 4) + h) * a.ld_partial + n) = s01 + s23;
     }
   }
 }
@@ -1738,27 +1749,26 @@ int launch_linear(const LinearParams& P, hipStream_t s, bool fast) {
 
 inline bool vec_ok(const float* p, int64_t ld) { return p && rr_aligned16(p) && (ld % 4 == 0); }
 
-template <int NT, int MODE>
+template <int NTP, int NT, int MODE, int WAVES>
 int launch_split_one(const LinearParams& P, hipStream_t s) {
   constexpr int smem = 2 * NT * 3 * 1024 + 16 * NT * 4;
   static bool configured = false;                      // > 64 KiB of LDS has to be asked for once per kernel
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NT, MODE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NTP, NT, MODE, WAVES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return RR_ERR_LAUNCH;
     configured = true;
   }
-  const unsigned grid = static_cast<unsigned>((P.a.M + S_BM - 1) / S_BM);
-  linear_split_kernel<NT, MODE><<<grid, S_THREADS, smem, s>>>(P);
+  const dim3 grid(static_cast<unsigned>((P.a.M + 16 * WAVES - 1) / (16 * WAVES)), static_cast<unsigned>((NTP + NT - 1) / NT));
+  linear_split_kernel<NTP, NT, MODE, WAVES><<<grid, 64 * WAVES, smem, s>>>(P);
   return rr_launch_status();
 }
-template <int NT>
+template <int NTP, int NT, int WAVES>
 int launch_split(const LinearParams& P, hipStream_t s) {
-  if (P.a.a_mask) return launch_split_one<NT, 2>(P, s);
-  if (P.a.a1_sub) return launch_split_one<NT, 1>(P, s);
-  return launch_split_one<NT, 0>(P, s);
+  if (P.a.a_mask) return launch_split_one<NTP, NT, 2, WAVES>(P, s);
+  if (P.a.a1_sub) return launch_split_one<NTP, NT, 1, WAVES>(P, s);
+  return launch_split_one<NTP, NT, 0, WAVES>(P, s);
 }
-
 }  // namespace
 
 extern "C" {
@@ -1827,13 +1837,13 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
     if (!fast || !vec_ok(a.colsum_partial, a.ld_partial)) return RR_ERR_ALIGN;
   }
   if (a.w_packed == 2) {                              // split terms only exist in the straight-line geometry
-    if (!fast || a.N > 304 || a.M >= (int64_t(1) << 31) * S_BM) return RR_ERR_ALIGN;
+    if (!fast || a.N > 304 || a.M >= (int64_t(1) << 31) * 128) return RR_ERR_ALIGN;
     if (a.dz_accumulate) return RR_ERR_UNSUPPORTED;
     P.t1 = r32(a.k1) / SK;
     P.t2 = r32(a.k2) / SK;
-    if (a.N <= 64) return launch_split<4>(P, s);
-    if (a.N <= 160) return launch_split<10>(P, s);
-    return launch_split<19>(P, s);
+    if (a.N <= 64) return launch_split<4, 4, 8>(P, s);
+    if (a.N <= 160) return launch_split<10, 10, 8>(P, s);
+    return launch_split<19, 19, 12>(P, s);
   }
   if (a.N <= 64) return launch_linear<4>(P, s, fast);
   if (a.N <= 160) return launch_linear<10>(P, s, fast);

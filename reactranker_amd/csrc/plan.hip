@@ -81,7 +81,8 @@ struct Ctx {
   int status;
   Arena ar;
   Streams s;
-  bool use_side, use_aux;
+  bool use_side, use_aux, aux_bwd;
+  hipStream_t cur;                    // stream of the backward chain being enqueued (main, or aux for the reactant pass)
   bool split;                         // encoder GEMMs on the bf16 matrix core (three exact bf16 terms per f32 operand)
   rr_pack_desc pq[RR_MAX_PACK];       // weight packs waiting for flush_packs()
   int npq;
@@ -151,8 +152,8 @@ void wgrad(Ctx& c, rr_wgrad_args& a) {
   a.workspace_bytes = wb;
   a.split = (c.split && a.M >= 8192) ? 1 : 0;           // the FFN head (one row per molecule) stays on the f32 matrix core
   if (!c.launch || c.status != RR_OK) return;
-  hipStream_t st = c.use_side ? c.s.side : c.s.main;
-  if (c.use_side) c.fail(stream_wait(c.s.side, c.s.main));
+  hipStream_t st = c.use_side ? c.s.side : c.cur;
+  if (c.use_side) c.fail(stream_wait(c.s.side, c.cur));
   c.fail(rr_linear_wgrad_f32(&a, st));
   if (c.status != RR_OK && getenv("RR_PLAN_DEBUG"))
     fprintf(stderr, "[rr plan] wgrad status %d: M %lld N %d k1 %d k2 %d ws %zu\n", c.status, (long long)a.M, a.N, a.k1, a.k2, wb);
@@ -398,7 +399,7 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
                   float p, const EncSaved& S, const float* dH, float sign, const EncGrads& G, int accumulate) {
   const int H = m.H, depth = m.depth;
   const float ks = 1.0f / (1.0f - p);
-  hipStream_t st = c.s.main;
+  hipStream_t st = c.cur;
   float* dz_o = c.ar.f(g.nA, H);
   float* d_a = c.ar.f(g.nA, H);
   float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
@@ -447,7 +448,7 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
                          const EncGrads& G, int accumulate) {
   const int H = m.H, depth = m.depth;
   const float ks = 1.0f / (1.0f - p);
-  hipStream_t st = c.s.main;
+  hipStream_t st = c.cur;
   float* dz_o = c.ar.f(g.nA, H);
   float* d_a = c.ar.f(g.nA, H);
   float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
@@ -698,9 +699,17 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
   E.wi = G.w[RR_G_ENC_WI]; E.bi = G.b[RR_G_ENC_WI]; E.wh = G.w[RR_G_ENC_WH]; E.bh = G.b[RR_G_ENC_WH];
   E.wo = G.w[RR_G_ENC_WO]; E.bo = G.b[RR_G_ENC_WO];
   // the two encoder passes share weights: the product pass writes the gradient buffers, the reactant pass accumulates
+  // The reactant pass may run on the aux stream beside the product pass (independent chains; their gather kernels are
+  // HBM-bound and co-reside with the other chain's one-workgroup-per-CU GEMMs).  Weight gradients of both go to the one
+  // side stream in issue order - product pass first - so the accumulation order does not depend on the overlap.
+  const bool fork = c.aux_bwd && c.use_aux;
+  if (c.launch && fork) c.fail(stream_wait(c.s.aux, main));
   mpn_backward(c, m, s.p, P.pk, wh_t, wo_t, p, P.p, d_diff, 1.0f, E, 0);
+  if (fork) c.cur = c.s.aux;
   if (s.mode == RR_STEP_PREFIX) mpn_backward_shared(c, m, s.u, s.r, s.bmap_t, s.bmap_t_cols, wh_t, wo_t, p, P.r, d_r, -1.0f, E, 1);
   else mpn_backward(c, m, s.r, P.pk, wh_t, wo_t, p, P.r, d_r, -1.0f, E, 1);
+  c.cur = main;
+  if (c.launch && fork) c.fail(stream_wait(main, c.s.aux));
   if (c.launch && c.use_side) c.fail(stream_wait(main, c.s.side));     // weight gradients are complete from here on
 }
 
@@ -754,6 +763,8 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
     Ctx c;
     c.launch = false; c.status = RR_OK; c.ar.base = nullptr; c.ar.off = 0; c.ar.cap = 0; c.ar.overflow = false; c.npq = 0;
     c.use_side = c.use_aux = false;
+    c.aux_bwd = false;
+    c.cur = nullptr;
     c.split = split != 0;
     Plan P;
     memset(&P, 0, sizeof(P));
@@ -776,8 +787,10 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
   c.split = (flags & RR_PLAN_F32_GEMM) == 0;
+  c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
+  c.cur = c.s.main;
   // the layout must fit BEFORE anything is launched (a dry pass costs microseconds)
   {
     Ctx d = c;
@@ -809,8 +822,10 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
   c.split = (flags & RR_PLAN_F32_GEMM) == 0;
+  c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
+  c.cur = c.s.main;
   Plan P;
   memset(&P, 0, sizeof(P));
   forward_all(c, *model, *step, P);                      // layout pass: re-derives the address of every saved activation

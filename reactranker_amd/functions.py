@@ -883,7 +883,7 @@ class StepPlan:
     @staticmethod
     def flags() -> int:
         return ((0 if SideStream.enabled else _lib.RR_PLAN_NO_SIDE_STREAM) | (0 if AuxStream.enabled else _lib.RR_PLAN_NO_AUX_STREAM) |
-                (0 if SplitGemm.enabled else _lib.RR_PLAN_F32_GEMM))
+                (0 if SplitGemm.enabled else _lib.RR_PLAN_F32_GEMM) | (_lib.RR_PLAN_AUX_BACKWARD if AuxStream.backward else 0))
 
 
 class ReactionModelFn(torch.autograd.Function):
