@@ -357,6 +357,7 @@ def main():
     ap.add_argument("--no-epoch", action="store_true", help="skip the streamed-from-disk epoch leg")
     ap.add_argument("--epoch-steps", type=int, default=200, help="DISTINCT packed steps written to shard files and streamed")
     ap.add_argument("--shard-workers", type=int, default=8, help="CPU processes packing the shard files")
+    ap.add_argument("--no-f32-path", action="store_true", help="skip the exact-f32-MFMA comparison leg")
     ap.add_argument("--no-side-stream", action="store_true", help="run weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="run the reactant encoder on the main stream")
     ap.add_argument("--aux-backward", action="store_true", help="also run the reactant encoder's backward on the aux stream")
@@ -518,6 +519,26 @@ def main():
                 roof_iso["peak_at_load_clock"] = load_clock
             roof_iso["note"] = "extra pass after the timed region, one stream (kernels do not overlap)"
 
+    # ---- the same step with every GEMM on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32): the split path's reference point
+    f32_path = None
+    if not args.no_f32_path:
+        Fn.SplitGemm.enabled = False
+        try:
+            for i in range(3):
+                R.train_step(pool[i % len(pool)])
+            n32 = min(args.steps, 15)
+            s32, per32, _ = R.timed(cyc(args.warmup + args.steps), n32)
+            t32 = torch.tensor([s32], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(t32, op=dist.ReduceOp.MAX)
+            f32_path = dict(queries_per_s=round(world * n32 * cfg["queries"] / float(t32.item()), 2),
+                            ms_per_step=round(float(t32.item()) / n32 * 1e3, 3), steps=n32, step_ms=step_stats(per32),
+                            note="same model state, same steps, SplitGemm.enabled = False (RR_PLAN_F32_GEMM): every GEMM on "
+                                 "v_mfma_f32_16x16x4_f32; `value` above is the three-bf16-term path")
+        finally:
+            Fn.SplitGemm.enabled = True
+        log(f"f32-MFMA path: {f32_path}")
+
     # ---- streamed epoch: the SAME training step fed from shard files on disk
     epoch = None
     if shard_dir is not None:
@@ -628,7 +649,7 @@ def main():
             "step_ms": step_stats(per_ms),
             "roofline": roof, "roofline_gather": roof_g, "roofline_isolated": roof_iso,
             "roofline_gather_isolated": roof_g_iso, "cpu_baseline": cpu,
-            "epoch_stream": epoch, "presets": presets or None, "dp": dp_info,
+            "f32_mfma_path": f32_path, "epoch_stream": epoch, "presets": presets or None, "dp": dp_info,
             "kernels": ktable, "kernels_isolated": ktable_iso, "final_loss": round(loss_val, 6),
             "host_prep_s": {"synthetic_generation": round(R.t_gen, 2), "native_pack_and_upload": round(R.t_pack, 2)},
         }

@@ -194,8 +194,11 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
                   (1 + (residual is not None) + (c_pre is not None)))
     if dz_out is not None:                              # side output d_input (+)= dZ: one write, one read when accumulating
         nbytes += 4 * M * k1 * (2 if dz_accumulate else 1)
-    kern = "linear_split_kernel" if int(w_packed) == 2 else ("linear_fast_kernel" if w_packed else "linear_kernel")
-    with _Timed(f"{kern}<{nt},{mode}>", 2 * M * N * kk, nbytes):
+    if int(w_packed) == 2:                              # the symbol rocprofv3 shows: <tiles packed, tiles per WG, mode, waves>
+        key = f"linear_split_kernel<{nt},{nt},{mode},{12 if nt == 19 else 8}>"
+    else:
+        key = f"{'linear_fast_kernel' if w_packed else 'linear_kernel'}<{nt},{mode}>"
+    with _Timed(key, 2 * M * N * kk, nbytes):
         check(lib().rr_linear_f32(C.byref(A), stream()), "rr_linear_f32")
     return out if colsum_w is None else (out, partial)
 

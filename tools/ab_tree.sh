@@ -16,7 +16,7 @@ else
   for rep in 1 2; do
     for t in $d $root; do
       echo -n "$(basename $t)  "
-      (cd $t && python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-fwd-only --no-epoch --no-presets "$@" 2>/dev/null) | \
+      (cd $t && python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-fwd-only --no-epoch --no-presets --no-f32-path "$@" 2>/dev/null) | \
         python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], 'ms/step', d.get('step_ms', {}).get('median'))"
     done
   done
