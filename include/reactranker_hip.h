@@ -182,7 +182,7 @@ typedef struct rr_pack_desc {
   const float* src;  int64_t ld_src;  int transpose, rows, c0, k1, k2;
   float* dst;
   int split;         /* 0: the f32 layout above.  1: dst (rr_split_weight_bytes(rows, k1, k2) bytes, 16-byte aligned,
-                        rows <= 304) receives every element of L as three bf16 terms t0 + t1 + t2 == L[r, c] EXACTLY
+                        rows <= 608) receives every element of L as three bf16 terms t0 + t1 + t2 == L[r, c] EXACTLY
                         (t0 = bf16(x), t1 = bf16(x - t0), t2 = x - t0 - t1), laid out as the LDS image of each
                         32-deep k-step of rr_linear_f32's w_packed = 2 path:
                         [k-step][16-column tile][term][lane 0..63][8 bf16], lane = (k-group of 8) * 16 + column */

@@ -627,11 +627,12 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackMany P) {
 // against an f64 GEMM is at or BELOW that of the f32 MFMA chain (tests/test_gpu_split.py measures both).  Six bf16
 // MFMAs cost 6/16 of the f32 MFMA's cycles for the same k: the kernel moves from MFMA-bound to HBM-bound.
 //
-// Geometry: workgroup = 8 waves x 16 rows = 128 rows x up to 304 output columns; the activation operand goes
+// Geometry: workgroup = 12 waves x 16 rows = 192 rows x up to 304 output columns; the activation operand goes
 // global -> registers (each lane loads the 8 consecutive k of ITS row that the MFMA layout hands it, fixes them up
 // - gather / subtract / ReLU mask - and splits them: every element is converted exactly once); the weight terms
 // are pre-split by rr_pack_weights (w_packed = 2) into the exact LDS image of a k-step (per column tile and term:
 // 64 lanes x 16 B, lane-linear) and stream L2 -> LDS by LDS-DMA, double buffered (2 x 57 KB: one workgroup per CU).
+// N > 304 (H = 600): two column blocks of 19 tiles (blockIdx.y), each streaming its own tiles of the image.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -946,7 +947,7 @@ __device__ __forceinline__ void split_one(float x, uint16_t& t0, uint16_t& t1, u
   t1 = static_cast<uint16_t>(p1 & 0xffffu);
   t2 = static_cast<uint16_t>(p2 & 0xffffu);
 }
-__host__ __device__ constexpr int split_nt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : 19); }
+__host__ __device__ constexpr int split_nt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : (N <= 304 ? 19 : 38)); }
 
 __device__ __forceinline__ void pack_split_elem(const rr_pack_desc& q, int64_t e) {
   const int nt = split_nt(q.rows);
@@ -1837,13 +1838,14 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
     if (!fast || !vec_ok(a.colsum_partial, a.ld_partial)) return RR_ERR_ALIGN;
   }
   if (a.w_packed == 2) {                              // split terms only exist in the straight-line geometry
-    if (!fast || a.N > 304 || a.M >= (int64_t(1) << 31) * 128) return RR_ERR_ALIGN;
+    if (!fast || a.N > 608 || a.M >= (int64_t(1) << 31) * 128) return RR_ERR_ALIGN;
     if (a.dz_accumulate) return RR_ERR_UNSUPPORTED;
     P.t1 = r32(a.k1) / SK;
     P.t2 = r32(a.k2) / SK;
     if (a.N <= 64) return launch_split<4, 4, 8>(P, s);
     if (a.N <= 160) return launch_split<10, 10, 8>(P, s);
-    return launch_split<19, 19, 12>(P, s);
+    if (a.N <= 304) return launch_split<19, 19, 12>(P, s);
+    return launch_split<38, 19, 12>(P, s);               // two column blocks of 19 tiles (H = 600)
   }
   if (a.N <= 64) return launch_linear<4>(P, s, fast);
   if (a.N <= 160) return launch_linear<10>(P, s, fast);
@@ -1867,7 +1869,7 @@ int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
   for (int i = 0; i < n; ++i) {
     const rr_pack_desc& q = descs[i];
     RR_CHECK_ARG(q.src && q.dst && q.rows >= 1 && q.c0 >= 0 && q.k1 >= 0 && q.k2 >= 0 && q.k1 + q.k2 >= 1 && q.ld_src >= 1);
-    RR_CHECK_ARG(q.split == 0 || (q.split == 1 && q.rows <= 304 && rr_aligned16(q.dst)));
+    RR_CHECK_ARG(q.split == 0 || (q.split == 1 && q.rows <= 608 && rr_aligned16(q.dst)));
     P.d[i] = q;
     const int64_t total = q.split ? static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * split_nt(q.rows) * 512
                                   : static_cast<int64_t>(q.rows) * (r16(q.k1) + r16(q.k2));
@@ -1888,7 +1890,7 @@ int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
 int64_t rr_packed_weight_ld(int k1, int k2) { return r16(k1) + r16(k2); }
 
 size_t rr_split_weight_bytes(int rows, int k1, int k2) {
-  if (rows < 1 || rows > 304 || k1 < 0 || k2 < 0 || k1 + k2 < 1) return 0;
+  if (rows < 1 || rows > 608 || k1 < 0 || k2 < 0 || k1 + k2 < 1) return 0;
   return static_cast<size_t>((r32(k1) + r32(k2)) / SK) * split_nt(rows) * 3 * 1024;
 }
 

@@ -106,7 +106,7 @@ void flush_packs(Ctx& c, hipStream_t st) {
 // big = the GEMM runs over atoms / bonds (the FFN head runs over molecules: a few thousand rows, launch-bound either way)
 Packed pack(Ctx& c, const rr_linear_w& L, int transpose, int rows, int c0, int k1, int k2, hipStream_t st, bool big = true) {
   Packed p;
-  const bool split = c.split && big && rows <= 304 && rows % 4 == 0;
+  const bool split = c.split && big && rows <= 608 && rows % 4 == 0;
   float* dst;
   if (split) {
     p.ld = 0;

@@ -195,7 +195,8 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     if dz_out is not None:                              # side output d_input (+)= dZ: one write, one read when accumulating
         nbytes += 4 * M * k1 * (2 if dz_accumulate else 1)
     if int(w_packed) == 2:                              # the symbol rocprofv3 shows: <tiles packed, tiles per WG, mode, waves>
-        key = f"linear_split_kernel<{nt},{nt},{mode},{12 if nt == 19 else 8}>"
+        ntp = 38 if N > 304 else nt
+        key = f"linear_split_kernel<{ntp},{nt},{mode},{12 if nt == 19 else 8}>"
     else:
         key = f"{'linear_fast_kernel' if w_packed else 'linear_kernel'}<{nt},{mode}>"
     with _Timed(key, 2 * M * N * kk, nbytes):
@@ -381,7 +382,7 @@ class LinW:
         self._t = {}
 
     def _pack(self, transpose: int, rows: int, c0: int, k1: int, k2: int):
-        split = SplitGemm.enabled and self.big and rows <= 304 and rows % 4 == 0
+        split = SplitGemm.enabled and self.big and rows <= 608 and rows % 4 == 0
         d = (_lib.PackDesc * 1)()
         if split:
             dst = torch.empty(int(lib().rr_split_weight_bytes(rows, k1, k2)), dtype=torch.uint8, device=self.w.device)

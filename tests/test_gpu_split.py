@@ -32,7 +32,7 @@ def _terms_to_f64(u16):
 
 @pytest.mark.parametrize("rows,k1,k2,transpose,c0", [(300, 300, 0, 0, 0), (300, 133, 300, 0, 0), (300, 147, 0, 0, 0),
                                                       (300, 300, 0, 1, 133), (64, 32, 0, 0, 0), (32, 300, 61, 0, 0),
-                                                      (160, 40, 0, 1, 0)])
+                                                      (160, 40, 0, 1, 0), (600, 600, 0, 0, 0), (600, 133, 600, 1, 0)])
 def test_pack_terms_are_exact_and_laid_out_as_documented(rows, k1, k2, transpose, c0):
     """t0 + t1 + t2 == w bit for bit (the sum is formed in f64, where it is exact), zeros in the padding, and the
     [k-step][16-column tile][term][lane][8] layout of include/reactranker_hip.h."""
@@ -44,7 +44,7 @@ def test_pack_terms_are_exact_and_laid_out_as_documented(rows, k1, k2, transpose
     w.flat[5::29] = 1e-30
     wd = torch.as_tensor(w).cuda()
     got = _pack_split(wd, transpose, rows, c0, k1, k2).cpu().numpy().view(np.uint16)
-    nt = 4 if rows <= 64 else (10 if rows <= 160 else 19)
+    nt = 4 if rows <= 64 else (10 if rows <= 160 else (19 if rows <= 304 else 38))
     t1 = (k1 + 31) // 32
     steps = t1 + (k2 + 31) // 32
     assert got.size == steps * nt * 3 * 512
