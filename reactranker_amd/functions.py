@@ -188,6 +188,8 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.c_pre, A.ld_pre = ptr(c_pre), _ld(c_pre)
     A.colsum_w, A.colsum_partial, A.ld_partial = ptr(colsum_w), ptr(partial), _ld(partial)
     nt = 4 if N <= 64 else (10 if N <= 160 else 19)
+    if M <= 8192 and not (w.dtype == torch.uint8 or int(w_packed) == 2):
+        nt = 4                                          # few rows: 64-column blocks (rr_linear_f32)
     mode = 2 if a_mask is not None else (1 if a1_sub is not None else 0)
     kk = k1 + k2
     nbytes = 4 * (M * kk * (2 if (a1_sub is not None or a_mask is not None) else 1) + N * kk + M * N *
