@@ -68,6 +68,14 @@ int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src,
  * The adjoint of index_select_ND (utils.py:176-193) for a GENERIC index tensor: autograd's index_select
  * backward is a scatter-add; here the sources of every destination row are listed (sorted by destination, stable)
  * and summed in that fixed order - no atomics, and no pad width to learn with a device->host sync. */
+/* out[r, 0:H] = sum_k (mask[j, :] > 0 ? src[j, :] * scale : 0), j = idx[r*K+k] >= 0 (src and mask share n_src / ld_src):
+ * rr_relu_bwd_f32 followed by rr_gather_sum_f32 in one pass, bit-identical to the sequence.  The shared-prefix reactant
+ * pass (train_listwise.py:188: every candidate carries its query's reactant) sums each distinct bond's gradient over
+ * its copies this way. */
+int rr_gather_sum_masked_f32(const float* src, const float* mask, int64_t n_src, int64_t ld_src,
+                             const int32_t* idx, int64_t n_out, int K, int H, float scale,
+                             float* out, int64_t ld_out, rr_stream_t stream);
+
 int rr_gather_sum_csr_f32(const float* src, int64_t n_src, int64_t ld_src,
                           const int32_t* offsets, const int32_t* idx, int64_t n_out, int H,
                           float* out, int64_t ld_out, rr_stream_t stream);

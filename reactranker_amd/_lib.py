@@ -114,6 +114,7 @@ _SIGS = {
     "rr_version": (i32, []),
     "rr_abi_struct_sizes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rr_gather_sum_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, c_stream]),
+    "rr_gather_sum_masked_f32": (i32, [c_f32p, c_f32p, i64, i64, c_i32p, i64, i32, i32, f32, c_f32p, i64, c_stream]),
     "rr_gather_sum_csr_f32": (i32, [c_f32p, i64, i64, c_i32p, c_i32p, i64, i32, c_f32p, i64, c_stream]),
     "rr_build_fbonds_f32": (i32, [c_f32p, i64, i64, i32, c_i32p, c_f32p, i64, i32, i64, c_f32p, i64, c_stream]),
     "rr_gather_diff_f32": (i32, [c_f32p, i64, i64, c_i32p, c_f32p, i64, i64, c_i32p, i64, i32, c_f32p, i64, c_stream]),

@@ -25,6 +25,50 @@ __device__ inline void st(float* p, typename Vec<VEC>::T v) {
 // out[r] = sum_k src[idx[r,k]]   (idx < 0 skipped)
 __device__ __attribute__((aligned(16))) const float gather_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
+// out[r] = sum_k (mask[j_k] > 0 ? src[j_k] * scale : 0): a ReLU / dropout backward (rr_relu_bwd_f32) folded into the gather
+// that consumes it - the same products in the same order, so the result equals the two-kernel sequence bit for bit, without
+// writing and re-reading the masked tensor.  Used where the masked tensor has no other reader: the shared-prefix reactant
+// pass sums each distinct bond's gradient over its (up to 64) copies.
+template <int VEC>
+__global__ void __launch_bounds__(256) gather_sum_masked_kernel(const float* __restrict__ src, const float* __restrict__ mask,
+                                                                int64_t ld_src, const int32_t* __restrict__ idx, int64_t n_out,
+                                                                int K, int HV, float scale, float* __restrict__ out,
+                                                                int64_t ld_out) {
+  using V = typename Vec<VEC>::T;
+  const int64_t total = n_out * HV;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  auto masked = [&](V v, V m) -> V {
+    if constexpr (VEC == 4) {
+      V r;
+      r.x = m.x > 0.f ? v.x * scale : 0.f; r.y = m.y > 0.f ? v.y * scale : 0.f;
+      r.z = m.z > 0.f ? v.z * scale : 0.f; r.w = m.w > 0.f ? v.w * scale : 0.f;
+      return r;
+    } else {
+      return m > 0.f ? v * scale : 0.f;
+    }
+  };
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / HV;
+    const int c = static_cast<int>(e - r * HV) * VEC;
+    const int32_t* ir = idx + r * K;
+    V acc = V(0.0f);
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {          // 8 independent row loads in flight; pad entries read the zero chunk
+      const int32_t j0 = ir[k], j1 = ir[k + 1], j2 = ir[k + 2], j3 = ir[k + 3];
+      const V v0 = ld<VEC>(j0 >= 0 ? src + j0 * ld_src + c : gather_zero), m0 = ld<VEC>(j0 >= 0 ? mask + j0 * ld_src + c : gather_zero);
+      const V v1 = ld<VEC>(j1 >= 0 ? src + j1 * ld_src + c : gather_zero), m1 = ld<VEC>(j1 >= 0 ? mask + j1 * ld_src + c : gather_zero);
+      const V v2 = ld<VEC>(j2 >= 0 ? src + j2 * ld_src + c : gather_zero), m2 = ld<VEC>(j2 >= 0 ? mask + j2 * ld_src + c : gather_zero);
+      const V v3 = ld<VEC>(j3 >= 0 ? src + j3 * ld_src + c : gather_zero), m3 = ld<VEC>(j3 >= 0 ? mask + j3 * ld_src + c : gather_zero);
+      acc = (((acc + masked(v0, m0)) + masked(v1, m1)) + masked(v2, m2)) + masked(v3, m3);
+    }
+    for (; k < K; ++k) {
+      const int32_t j = ir[k];
+      acc = acc + masked(ld<VEC>(j >= 0 ? src + j * ld_src + c : gather_zero), ld<VEC>(j >= 0 ? mask + j * ld_src + c : gather_zero));
+    }
+    st<VEC>(out + r * ld_out + c, acc);
+  }
+}
+
 template <int VEC>
 __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict__ src, int64_t ld_src,
                                                          const int32_t* __restrict__ idx, int64_t n_out, int K,
@@ -319,6 +363,23 @@ int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src, co
   } else {
     gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256) + H, 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out,
                                                                          row0_partial, n_partial, ld_partial);
+  }
+  return rr_launch_status();
+}
+
+int rr_gather_sum_masked_f32(const float* src, const float* mask, int64_t n_src, int64_t ld_src, const int32_t* idx,
+                             int64_t n_out, int K, int H, float scale, float* out, int64_t ld_out, rr_stream_t stream) {
+  RR_CHECK_ARG(src && mask && idx && out && n_src >= 0 && n_out >= 1 && K >= 1 && H >= 1 && ld_src >= H && ld_out >= H);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(mask) &&
+                   rr_aligned16(out);
+  if (vec) {
+    const int HV = H / 4;
+    gather_sum_masked_kernel<4><<<rr_grid_for(n_out * HV, 256), 256, 0, s>>>(src, mask, ld_src, idx, n_out, K, HV, scale, out,
+                                                                             ld_out);
+  } else {
+    gather_sum_masked_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, mask, ld_src, idx, n_out, K, H, scale, out,
+                                                                            ld_out);
   }
   return rr_launch_status();
 }

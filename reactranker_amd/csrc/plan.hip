@@ -495,10 +495,9 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     d_msg = bond_adjoint(c, g, H, d_min, partb, st);
   }
   // ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
-  float* dz1_full = c.ar.f(g.nB, H);
-  RR_TRY(c, rr_relu_bwd_f32(d_msg, S.msgs[1], ks, dz1_full, nullptr, g.nB * static_cast<int64_t>(H), st));
+  // dz1 of every copy is read once, by the sum over the copies: mask and gather in one pass (no [nB, H] round trip)
   float* dz1_u = c.ar.f(gu.nB, H);
-  gather_sum(c, dz1_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, dz1_u, H, st);      // sum over the copies
+  RR_TRY(c, rr_gather_sum_masked_f32(d_msg, S.msgs[1], g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, ks, dz1_u, H, st));
   float* d_inp_u = c.ar.f(gu.nB, H);
   if (have_full) {
     gather_sum(c, d_inp_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, d_inp_u, H, st);

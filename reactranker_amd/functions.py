@@ -112,6 +112,18 @@ def gather_sum(src: torch.Tensor, idx: torch.Tensor, H: int, out: torch.Tensor =
     return out
 
 
+def gather_sum_masked(src, mask, scale: float, idx, H: int, out=None):
+    """out[r] = sum_k (mask[idx[r,k]] > 0 ? src[idx[r,k]] * scale : 0): relu_bwd + gather_sum in one pass, bit-identical."""
+    n_out, K = idx.shape
+    if out is None:
+        out = _new(src, n_out, H)
+    assert mask.shape == src.shape and mask.stride(0) == src.stride(0)
+    with _Timed("gather_sum_masked_kernel", 0, 4 * (2 * src.shape[0] * H + n_out * H + n_out * K)):
+        check(lib().rr_gather_sum_masked_f32(ptr(src), ptr(mask), src.shape[0], _ld(src), ptr(idx), n_out, K, H, float(scale),
+                                             ptr(out), _ld(out), stream()), "rr_gather_sum_masked_f32")
+    return out
+
+
 def gather_sum_csr(src: torch.Tensor, offsets: torch.Tensor, idx: torch.Tensor, n_out: int, H: int) -> torch.Tensor:
     """out[r] = sum of src[idx[j]] for j in [offsets[r], offsets[r+1]) — adjoint of a gather through a generic index."""
     out = _new(src, n_out, H)
@@ -589,8 +601,7 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
         d_inp_full = dz if d_inp_full is None else axpby(1.0, d_inp_full, 1.0, dz)   # fresh buffer (side-stream readers)
         d_msg = bond_message_adjoint(d_min, g, H, part)
     # ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
-    dz1_full = relu_bwd(d_msg, msgs[1], ks)                           # (msgs[1] > 0) <=> kept and z1 > 0
-    dz1_u = gather_sum(dz1_full, bmap_t, H)                           # sum over the copies
+    dz1_u = gather_sum_masked(d_msg, msgs[1], ks, bmap_t, H)          # (msgs[1] > 0) <=> kept and z1 > 0; sum over the copies
     if d_inp_full is not None:
         d_inp_u = gather_sum(d_inp_full, bmap_t, H)
         axpby(1.0, d_inp_u, 1.0, dz1_u, out=d_inp_u)

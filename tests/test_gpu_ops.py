@@ -312,3 +312,20 @@ def test_linear_weighted_colsum_side_output_and_padrow_gather(M, N, K):
     ref0 = part[:, :N].double().sum(0)
     assert float((gs[0].double() - ref0).abs().max()) <= 2e-6 * scale
     assert torch.equal(Fn.gather_sum(out, idx.cuda(), N, row0_partial=part)[0], gs[0])     # fixed order: bit-stable
+
+
+@pytest.mark.parametrize("H", [300, 30])
+@pytest.mark.parametrize("K", [1, 3, 64])
+def test_gather_sum_masked_equals_relu_backward_then_gather(H, K):
+    """The fused pass of the shared-prefix backward: bit-identical to rr_relu_bwd_f32 followed by rr_gather_sum_f32."""
+    rng = np.random.default_rng(H + K)
+    n_src, n_out = 1543, 97
+    src = dev(rng.standard_normal((n_src, H)).astype(np.float32))
+    mask = dev(np.maximum(rng.standard_normal((n_src, H)), 0).astype(np.float32))
+    idx = rng.integers(-1, n_src, size=(n_out, K)).astype(np.int32)
+    idx[0] = -1
+    got = Fn.gather_sum_masked(src, mask, 1.0 / 0.9, dev(idx), H)
+    ref = Fn.gather_sum(Fn.relu_bwd(src, mask, 1.0 / 0.9), dev(idx), H)
+    assert torch.equal(got, ref)
+    want = np.where(idx[..., None] >= 0, np.where(mask.cpu().numpy() > 0, src.cpu().numpy() * np.float32(1.0 / 0.9), 0)[np.maximum(idx, 0)], 0).sum(1)
+    close(got, want, what="masked gather")
