@@ -168,9 +168,17 @@ typedef struct rr_linear_args {
                                                        receives sum_a npad[a] * d_out[a]) falls out of the GEMM that
                                                        produces d_out instead of a separate pass over it; the partial
                                                        rows are summed, in order, by rr_gather_sum_padrow_f32. */
+  uint8_t* mask_bits_out;                           /* optional fourth output (w_packed = 2, N % 4 == 0): the sign of every
+                                                       stored element, 1 bit each, rr_mask_bits_row_bytes(N) bytes per row:
+                                                       per block of up to 304 columns 2 x 20 bytes - byte 20*h + t holds
+                                                       columns 16*t + 8*h .. + 7 (bit e = column + e).  What a later
+                                                       dX GEMM needs of this activation (a_mask > 0), at 1/32 of the bytes */
+  const uint8_t* a_mask_bits;                       /* alternative to a_mask (w_packed = 2, k2 = 0, k1 % 4 == 0): such a bit
+                                                       image over the k1 columns of A; a_mask is then not read */
 } rr_linear_args;
 
 int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream);
+int64_t rr_mask_bits_row_bytes(int N);
 /* Row blocks (= partial rows written through colsum_partial) of an M-row call. */
 int64_t rr_linear_colsum_rows(int64_t M);
 

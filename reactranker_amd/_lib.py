@@ -37,6 +37,7 @@ class LinearArgs(C.Structure):
         ("c", c_f32p), ("ldc", i64),
         ("c_pre", c_f32p), ("ld_pre", i64),
         ("colsum_w", c_f32p), ("colsum_partial", c_f32p), ("ld_partial", i64),
+        ("mask_bits_out", C.c_void_p), ("a_mask_bits", C.c_void_p),
     ]
 
 
@@ -125,6 +126,7 @@ _SIGS = {
     "rr_linear_colsum_rows": (i64, [i64]),
     "rr_gather_sum_padrow_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, c_f32p, i64, c_stream]),
     "rr_packed_weight_ld": (i64, [i32, i32]),
+    "rr_mask_bits_row_bytes": (i64, [i32]),
     "rr_split_weight_bytes": (C.c_size_t, [i32, i32, i32]),
     "rr_pack_weight_f32": (i32, [c_f32p, i64, i32, i32, i32, i32, i32, c_f32p, c_stream]),
     "rr_pack_weights_f32": (i32, [C.c_void_p, i32, c_stream]),

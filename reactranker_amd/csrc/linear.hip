@@ -53,6 +53,10 @@ typedef const __attribute__((address_space(1))) f32x4* rr_gptr4;
 typedef const __attribute__((address_space(1))) int32_t* rr_gptri;
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(rr_gptr4)(p); }
 __device__ __forceinline__ int32_t ldgi(const int32_t* p) { return *(rr_gptri)(p); }
+typedef const __attribute__((address_space(1))) uint8_t* rr_gptrb;
+__device__ __forceinline__ uint32_t ldgb(const uint8_t* p) { return *(rr_gptrb)(p); }
+// bytes per row of a packed sign mask over N columns: 40 per block of up to 304 columns (2 halves x 20: 19 tile bytes + pad)
+__host__ __device__ constexpr int64_t mask_bits_row(int N) { return 40 * ((N + 303) / 304); }
 
 // LDS-DMA: 16 bytes per lane, global -> LDS at (wave-uniform byte address lds_dst) + lane * 16, no VGPR
 // destination.  Written as asm so that hipcc does not track it: its own bookkeeping treats an LDS-DMA in
@@ -685,6 +689,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   const float* rowp1 = nullptr;
   const float* rowp2 = nullptr;
   const float* subp = nullptr;                         // MODE 1: subtract source, MODE 2: mask source
+  const uint8_t* bitrow = nullptr;                     // MODE 3: the mask as one bit per element (rr_linear_args.a_mask_bits)
   {
     const bool g1 = a.k1 > 0 && a.a1_idx != nullptr;
     const bool g2 = MODE == 1 && a.k1 > 0 && a.a1_sub != nullptr && a.a1_sub_idx != nullptr;
@@ -705,12 +710,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
           }
         }
         if (MODE == 2) subp = a.a_mask + m * a.ld_mask;
+        if (MODE == 3) bitrow = a.a_mask_bits + m * mask_bits_row(a.k1);
       }
       if (a.k2 > 0) rowp2 = a.a2 + m * a.lda2;
     }
   }
   float* dzrow = nullptr;                              // MODE 2 side output: dz_out (+)= masked operand
-  if (MODE == 2 && a.dz_out && row_ok && blockIdx.y == 0) dzrow = a.dz_out + m * a.ld_dz;
+  if ((MODE == 2 || MODE == 3) && a.dz_out && row_ok && blockIdx.y == 0) dzrow = a.dz_out + m * a.ld_dz;
 
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
   const float* const wlane = a.w + t0 * 768 + lane * 4;   // this workgroup's tiles of a step; 16 B per lane inside a 1 KiB block
@@ -723,6 +729,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   const int nk = P.t1 + P.t2;
   // operand chunks in flight: two k-steps (slot = step & 1), so a load has two MFMA blocks to land; the weight image one
   f32x4 ra[NT == NTP ? 2 : 1][2], rs[NT == NTP ? 2 : 1][2];
+  uint32_t rb[2] = {0u, 0u};                           // MODE 3: the 8 mask bits of a step's chunk pair
   u32x4 x0, x1, x2;                                    // the three bf16 terms of the current step's operand
 
   auto issue_x = [&](int s, int slot) {                // pure loads (unconditional, from a selected address)
@@ -732,10 +739,16 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     const int ks = seg1 ? a.k1 : a.k2;
     ra[slot][0] = ldg4((p != nullptr && kl < ks) ? p + kl : dummy);
     ra[slot][1] = ldg4((p != nullptr && kl + 4 < ks) ? p + kl + 4 : dummy);
-    if (MODE != 0) {
+    if (MODE == 1 || MODE == 2) {
       const bool oks = seg1 && subp != nullptr;
       rs[slot][0] = ldg4((oks && kl < ks) ? subp + kl : dummy);
       rs[slot][1] = ldg4((oks && kl + 4 < ks) ? subp + kl + 4 : dummy);
+    }
+    if (MODE == 3) {                                   // byte (column block, half tile, tile) holds k = kl .. kl+7, bit e <-> kl + e
+      const int tc = 2 * s + (fkq >> 1);
+      const int y = tc / 19;
+      const uint8_t* q = bitrow + y * 40 + (fkq & 1) * 20 + (tc - 19 * y);
+      rb[slot] = ldgb((seg1 && bitrow != nullptr && kl < ks) ? q : reinterpret_cast<const uint8_t*>(dummy));
     }
   };
   auto issue_w = [&](int s) {                          // weight image of step s: NT * 3 LDS-DMA blocks of 1 KiB over the waves
@@ -775,12 +788,21 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
         v1[e] = (oks && kl + 4 + e < ks && rs[slot][1][e] > 0.f) ? v1[e] * a.mask_scale : 0.f;
       }
     }
+    if (MODE == 3) {
+      const bool oks = seg1 && (bitrow != nullptr);
+      const uint32_t bits = rb[slot];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = (oks && kl + e < ks && ((bits >> e) & 1u)) ? v0[e] * a.mask_scale : 0.f;
+        v1[e] = (oks && kl + 4 + e < ks && ((bits >> (4 + e)) & 1u)) ? v1[e] * a.mask_scale : 0.f;
+      }
+    }
     uint32_t t0, t1, t2;
     split_pair(v0.x, v0.y, t0, t1, t2); x0.x = t0; x1.x = t1; x2.x = t2;
     split_pair(v0.z, v0.w, t0, t1, t2); x0.y = t0; x1.y = t1; x2.y = t2;
     split_pair(v1.x, v1.y, t0, t1, t2); x0.z = t0; x1.z = t1; x2.z = t2;
     split_pair(v1.z, v1.w, t0, t1, t2); x0.w = t0; x1.w = t1; x2.w = t2;
-    if (MODE == 2) {                                   // side output (k1 % 4 == 0: chunks are whole).  Stored HERE, after the
+    if (MODE == 2 || MODE == 3) {                      // side output (k1 % 4 == 0: chunks are whole).  Stored HERE, after the
       if (dzrow != nullptr && seg1) {                  // step's load wait: the store then has the whole next MFMA block to retire
         if (kl < ks) *reinterpret_cast<f32x4*>(dzrow + kl) = v0;
         if (kl + 4 < ks) *reinterpret_cast<f32x4*>(dzrow + kl + 4) = v1;
@@ -817,7 +839,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   };
   // one k-step with compile-time slots.  vmcnt retires in issue order: the operand loads of step s+2 are issued AFTER the
   // weight image of step s+1, so "all but the youngest NX" = image landed, step s+1's chunks landed, step s+2's in flight.
-  constexpr int NX = MODE == 0 ? 2 : 4;                // vector-memory instructions of one issue_x
+  constexpr int NX = MODE == 0 ? 2 : (MODE == 3 ? 3 : 4);   // vector-memory instructions of one issue_x
   constexpr bool DEEP = NT == NTP;                     // the two-workgroups-per-CU geometry has 128 registers: one step ahead
   auto step = [&](int s, int slot) {
     const bool more = s + 1 < nk, more2 = s + 2 < nk;
@@ -830,6 +852,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     mfma_block(s);
     if (DEEP && more2) {
       if (NX == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (NX == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       rr_wait_vm0();
@@ -879,6 +902,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     return v;
   };
   float* prow = a.c_pre ? a.c_pre + mc * a.ld_pre : nullptr;
+  // optional fourth output: sign bits of what was stored (the mask a later dX GEMM needs: 1 bit instead of 4 bytes).
+  // A lane holds 4 columns of a tile; lanes fkq and fkq^1 (16 lanes apart) make a byte = 8 consecutive columns, the
+  // even one collects its 19 bytes in 5 registers and stores them once.
+  const bool mb_on = a.mask_bits_out != nullptr;
+  uint32_t mb[5] = {0u, 0u, 0u, 0u, 0u};
   const bool cs_on = a.colsum_partial != nullptr;
   const float wrow = (cs_on && row_ok) ? a.colsum_w[mc] : 0.f;
   float* const cs_lds = reinterpret_cast<float*>(smem);    // [waves][BN], the (now idle) weight image
@@ -908,6 +936,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       if (tc + D < NT) ring[(tc + D) % (D + 1)] = ldres(tc + D);
       if (prow != nullptr && row_ok && n < a.N) *reinterpret_cast<f32x4*>(prow + n) = v;
       const f32x4 stored = finish(v, n);
+      if (mb_on) {
+        const uint32_t nib = (stored.x > 0.f ? 1u : 0u) | (stored.y > 0.f ? 2u : 0u) | (stored.z > 0.f ? 4u : 0u) | (stored.w > 0.f ? 8u : 0u);
+        const uint32_t other = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, static_cast<int>(nib)));
+        mb[tc >> 2] |= (nib | (other << 4)) << (8 * (tc & 3));
+      }
       if (cs_on) {
         f32x4 t = stored * wrow;
 #pragma unroll
@@ -922,6 +955,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
         if (fr == 15) *reinterpret_cast<f32x4*>(cs_lds + wave * BN + tc * 16 + nq) = t;
       }
     }
+  }
+  if (mb_on && row_ok && (fkq & 1) == 0) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(a.mask_bits_out + m * mask_bits_row(a.N) + blockIdx.y * 40 + (fkq >> 1) * 20);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) d[i] = mb[i];
   }
   if (cs_on) {                                         // one partial row per 64 rows (rr_linear_colsum_rows) = per 4 waves
     __syncthreads();
@@ -1776,6 +1814,7 @@ int launch_split_one(const LinearParams& P, hipStream_t s) {
 }
 template <int NTP, int NT, int WAVES>
 int launch_split(const LinearParams& P, hipStream_t s) {
+  if (P.a.a_mask_bits) return launch_split_one<NTP, NT, 3, WAVES>(P, s);
   if (P.a.a_mask) return launch_split_one<NTP, NT, 2, WAVES>(P, s);
   if (P.a.a1_sub) return launch_split_one<NTP, NT, 1, WAVES>(P, s);
   return launch_split_one<NTP, NT, 0, WAVES>(P, s);
@@ -1804,7 +1843,9 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   RR_CHECK_ARG(!a.a_mask || (a.k2 == 0 && !a.a1_sub && !a.a1_idx && a.ld_mask >= a.k1));
   RR_CHECK_ARG(!a.residual || a.ldr >= a.N);
   RR_CHECK_ARG(!a.c_pre || a.ld_pre >= a.N);
-  RR_CHECK_ARG(!a.dz_out || (a.a_mask && a.ld_dz >= a.k1));
+  RR_CHECK_ARG(!a.dz_out || ((a.a_mask || a.a_mask_bits) && a.ld_dz >= a.k1));
+  RR_CHECK_ARG(!a.a_mask_bits || (a.w_packed == 2 && a.k2 == 0 && !a.a1_sub && !a.a1_idx && a.k1 % 4 == 0));
+  RR_CHECK_ARG(!a.mask_bits_out || (a.w_packed == 2 && a.N % 4 == 0));
   RR_CHECK_ARG(a.act == RR_ACT_NONE || a.act == RR_ACT_RELU);
   RR_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f);
   RR_CHECK_ARG(a.M < (int64_t(1) << 31) * BM);
@@ -1901,6 +1942,8 @@ int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
 }
 
 int64_t rr_packed_weight_ld(int k1, int k2) { return r16(k1) + r16(k2); }
+
+int64_t rr_mask_bits_row_bytes(int N) { return N < 1 ? 0 : mask_bits_row(N); }
 
 size_t rr_split_weight_bytes(int rows, int k1, int k2) {
   if (rows < 1 || rows > 608 || k1 < 0 || k2 < 0 || k1 + k2 < 1) return 0;

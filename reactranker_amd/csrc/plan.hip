@@ -125,6 +125,12 @@ Packed pack(Ctx& c, const rr_linear_w& L, int transpose, int rows, int c0, int k
   return p;
 }
 
+// sign-bit image of an [rows, N] activation produced by a split GEMM (null: the consumer reads the f32 tensor instead)
+uint8_t* mask_bits(Ctx& c, const Packed& producer, int64_t rows, int N) {
+  if (producer.mode != 2) return nullptr;
+  return reinterpret_cast<uint8_t*>(c.ar.f(rows, rr_mask_bits_row_bytes(N) / 4));
+}
+
 rr_linear_args LA(int64_t M, int N) {
   rr_linear_args a;
   memset(&a, 0, sizeof(a));
@@ -137,7 +143,10 @@ rr_linear_args LA(int64_t M, int N) {
 
 // Packs are queued and issued together (rr_pack_weights_f32: one launch for up to 16 weights) by flush_packs().
 
-void set_w(rr_linear_args& a, const Packed& p) { a.w = p.w; a.ldw = p.ld; a.w_packed = p.mode; }
+void set_w(rr_linear_args& a, const Packed& p) {
+  a.w = p.w; a.ldw = p.ld; a.w_packed = p.mode;
+  if (p.mode != 2) a.a_mask_bits = nullptr;            // only the split GEMM reads sign-bit masks (a_mask stays set)
+}
 
 void gather_sum(Ctx& c, const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K, int H,
                 float* out, int64_t ld_out, hipStream_t st, const float* part = nullptr, int64_t n_part = 0, int64_t ld_part = 0) {
@@ -171,6 +180,8 @@ rr_wgrad_args WA(int64_t M, int N, const float* dy, int64_t ld_dy, float* dw, in
 constexpr int MAXD = 16;             // message-passing depth supported by a plan
 
 struct EncSaved {                    // mpn_forward / mpn_forward_shared
+  uint8_t* bits[MAXD];               // sign bits of msgs[i] where a split GEMM produced it (rr_linear_args.mask_bits_out), else null
+  uint8_t* bits_h;
   float* msgs[MAXD];                 // [nB, H] each (shared mode: msgs[0] unused)
   float* amsgs[MAXD];                // [nA, H]
   float* a_last;
@@ -178,6 +189,8 @@ struct EncSaved {                    // mpn_forward / mpn_forward_shared
   float *msg0_u, *a0_u;              // shared prefix (distinct molecules)
 };
 struct DiffSaved {
+  uint8_t* bits[MAXD];
+  uint8_t* bits_hid;
   float* msgs[MAXD];
   float* amsgs[MAXD];
   float* a_last;
@@ -224,6 +237,7 @@ void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk
     set_w(a, pk.enc_wh); a.bias = m.enc_wh.b; a.residual = inp; a.ldr = H; a.act = RR_ACT_RELU;
     a.drop_p = p; a.drop_seed = site_seed(seed, it);
     a.c = S.msgs[it + 1]; a.ldc = H;
+    S.bits[it + 1] = mask_bits(c, pk.enc_wh, g.nB, H); a.mask_bits_out = S.bits[it + 1];
     RR_TRY(c, rr_linear_f32(&a, st));                                                   // :91-97
   }
   S.a_last = c.ar.f(g.nA, H);
@@ -233,6 +247,7 @@ void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk
   a.a1 = g.f_atoms; a.lda1 = g.ld_fa; a.k1 = m.atom_fdim; a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
   set_w(a, pk.enc_wo); a.bias = m.enc_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 1000);
   a.c = S.h; a.ldc = H;
+  S.bits_h = mask_bits(c, pk.enc_wo, g.nA, H); a.mask_bits_out = S.bits_h;
   RR_TRY(c, rr_linear_f32(&a, st));                                                     // :103-105
 }
 
@@ -273,6 +288,7 @@ void mpn_forward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_
     set_w(a, pk.enc_wh); a.bias = m.enc_wh.b; a.residual = inp_u; a.ldr = H; a.residual_idx = bmap; a.act = RR_ACT_RELU;
     a.drop_p = p; a.drop_seed = site_seed(seed, it);
     a.c = S.msgs[it + 1]; a.ldc = H;
+    S.bits[it + 1] = mask_bits(c, pk.enc_wh, g.nB, H); a.mask_bits_out = S.bits[it + 1];
     RR_TRY(c, rr_linear_f32(&a, st));
   }
   S.a_last = c.ar.f(g.nA, H);
@@ -282,6 +298,7 @@ void mpn_forward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_
   a.a1 = g.f_atoms; a.lda1 = g.ld_fa; a.k1 = m.atom_fdim; a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
   set_w(a, pk.enc_wo); a.bias = m.enc_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 1000);
   a.c = S.h; a.ldc = H;
+  S.bits_h = mask_bits(c, pk.enc_wo, g.nA, H); a.mask_bits_out = S.bits_h;
   RR_TRY(c, rr_linear_f32(&a, st));
 }
 
@@ -310,6 +327,7 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
       set_w(a, pk.dif_wh); a.bias = m.dif_wh.b; a.residual = inp; a.ldr = H; a.act = RR_ACT_RELU;
       a.drop_p = p; a.drop_seed = site_seed(seed, 2001 + it);
       a.c = S.msgs[it + 1]; a.ldc = H;
+      S.bits[it + 1] = mask_bits(c, pk.dif_wh, g.nA, H); a.mask_bits_out = S.bits[it + 1];
       RR_TRY(c, rr_linear_f32(&a, st));                                                 // :202-213
     }
     S.a_last = c.ar.f(g.nA, H);
@@ -320,6 +338,7 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
     a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
     set_w(a, pk.dif_wo); a.bias = m.dif_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 3000);
     a.c = S.hid; a.ldc = H;
+    S.bits_hid = mask_bits(c, pk.dif_wo, g.nA, H); a.mask_bits_out = S.bits_hid;
     RR_TRY(c, rr_linear_f32(&a, st));                                                   // :217-219
   } else {
     S.a_last = nullptr;
@@ -405,7 +424,7 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
   float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
   {
     rr_linear_args a = LA(g.nA, H);
-    a.a1 = dH; a.lda1 = H; a.k1 = H; a.a_mask = S.h; a.ld_mask = H; a.mask_scale = sign * ks;
+    a.a1 = dH; a.lda1 = H; a.k1 = H; a.a_mask = S.h; a.a_mask_bits = S.bits_h; a.ld_mask = H; a.mask_scale = sign * ks;
     a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_t);
     a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
     a.c = d_a; a.ldc = H;
@@ -425,7 +444,7 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
     float* d_min = c.ar.f(g.nB, H);
     float* partb = c.ar.f(rr_linear_colsum_rows(g.nB), r4(H));
     rr_linear_args a = LA(g.nB, H);
-    a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.ld_mask = H; a.mask_scale = ks;
+    a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.a_mask_bits = S.bits[it + 1]; a.ld_mask = H; a.mask_scale = ks;
     a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
     a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
     a.c = d_min; a.ldc = H;
@@ -454,7 +473,7 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
   float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
   {
     rr_linear_args a = LA(g.nA, H);
-    a.a1 = dH; a.lda1 = H; a.k1 = H; a.a_mask = S.h; a.ld_mask = H; a.mask_scale = sign * ks;
+    a.a1 = dH; a.lda1 = H; a.k1 = H; a.a_mask = S.h; a.a_mask_bits = S.bits_h; a.ld_mask = H; a.mask_scale = sign * ks;
     a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_t);
     a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
     a.c = d_a; a.ldc = H;
@@ -475,7 +494,7 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     float* d_min = c.ar.f(g.nB, H);
     float* partb = c.ar.f(rr_linear_colsum_rows(g.nB), r4(H));
     rr_linear_args a = LA(g.nB, H);
-    a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.ld_mask = H; a.mask_scale = ks;
+    a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.a_mask_bits = S.bits[it + 1]; a.ld_mask = H; a.mask_scale = ks;
     a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
     a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
     a.c = d_min; a.ldc = H;
@@ -543,7 +562,7 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
     d_x = c.ar.f(g.nA, H);
     {
       rr_linear_args a = LA(g.nA, H);
-      a.a1 = d_hid; a.lda1 = H; a.k1 = H; a.a_mask = S.hid; a.ld_mask = H; a.mask_scale = ks;
+      a.a1 = d_hid; a.lda1 = H; a.k1 = H; a.a_mask = S.hid; a.a_mask_bits = S.bits_hid; a.ld_mask = H; a.mask_scale = ks;
       a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_x); a.c = d_x; a.ldc = H;
       RR_TRY(c, rr_linear_f32(&a, st));
     }
@@ -557,7 +576,7 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
     float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
     {
       rr_linear_args a = LA(g.nA, H);
-      a.a1 = d_hid; a.lda1 = H; a.k1 = H; a.a_mask = S.hid; a.ld_mask = H; a.mask_scale = ks;
+      a.a1 = d_hid; a.lda1 = H; a.k1 = H; a.a_mask = S.hid; a.a_mask_bits = S.bits_hid; a.ld_mask = H; a.mask_scale = ks;
       set_w(a, wo_a); a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
       a.c = d_a; a.ldc = H;
       RR_TRY(c, rr_linear_f32(&a, st));
@@ -572,7 +591,7 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
       float* d_a2 = c.ar.f(g.nA, H);
       float* part2 = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
       rr_linear_args a = LA(g.nA, H);
-      a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.ld_mask = H; a.mask_scale = ks;
+      a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.a_mask_bits = S.bits[it + 1]; a.ld_mask = H; a.mask_scale = ks;
       a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
       a.colsum_w = g.npad; a.colsum_partial = part2; a.ld_partial = r4(H);
       a.c = d_a2; a.ldc = H;

@@ -174,7 +174,8 @@ def weighted_colsum(x, w, H: int, out, accumulate: bool):
 
 def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub_idx=None, a2=None, k2=0, a_mask=None,
            mask_scale=1.0, ldw=None, w_packed=False, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0,
-           out=None, c_pre=None, dz_out=None, dz_accumulate=False, residual_idx=None, colsum_w=None):
+           out=None, c_pre=None, dz_out=None, dz_accumulate=False, residual_idx=None, colsum_w=None, mask_bits_out=None,
+           a_mask_bits=None):
     """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h).
     colsum_w [M]: also returns the per-row-block partial sums of colsum_w[m] * out[m, :]  ->  (out, partial)."""
     ref = a1 if a1 is not None else a2
@@ -199,10 +200,11 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.c, A.ldc = ptr(out), _ld(out)
     A.c_pre, A.ld_pre = ptr(c_pre), _ld(c_pre)
     A.colsum_w, A.colsum_partial, A.ld_partial = ptr(colsum_w), ptr(partial), _ld(partial)
+    A.mask_bits_out, A.a_mask_bits = ptr(mask_bits_out), ptr(a_mask_bits)    # sign-bit images (split GEMM only)
     nt = 4 if N <= 64 else (10 if N <= 160 else 19)
     if M <= 8192 and not (w.dtype == torch.uint8 or int(w_packed) == 2):
         nt = 4                                          # few rows: 64-column blocks (rr_linear_f32)
-    mode = 2 if a_mask is not None else (1 if a1_sub is not None else 0)
+    mode = 3 if a_mask_bits is not None else (2 if a_mask is not None else (1 if a1_sub is not None else 0))
     kk = k1 + k2
     nbytes = 4 * (M * kk * (2 if (a1_sub is not None or a_mask is not None) else 1) + N * kk + M * N *
                   (1 + (residual is not None) + (c_pre is not None)))

@@ -211,3 +211,30 @@ def test_split_and_f32_paths_give_the_same_ranking_and_scores_within_tolerance()
         # two f32 evaluations with different summation orders: gradients of this step cancel to ~1e-3 of their terms, so
         # each path is ~1e-4 of max|g| away from exact arithmetic (the per-GEMM tests above bound each GEMM by itself)
         assert ((sp[2][k] - f32p[2][k]).abs().max() / s).item() <= 5e-4, k
+
+
+@pytest.mark.parametrize("M,H", [(1, 300), (193, 300), (5000, 300), (777, 600), (500, 64)])
+def test_sign_bit_masks_round_trip_through_the_split_gemm(M, H):
+    """mask_bits_out of a forward GEMM is the sign of what it stored, in the documented layout, and a dX GEMM that reads it
+    (a_mask_bits) equals the one that reads the f32 activation bit for bit - dZ side output included."""
+    torch.manual_seed(M + H)
+    dev = "cuda"
+    W = torch.randn(H, H, device=dev) / 17
+    b = torch.randn(H, device=dev)
+    x = torch.randn(M, H, device=dev)
+    L = Fn.LinW(W, b)
+    rowb = int(lib().rr_mask_bits_row_bytes(H))
+    bits = torch.zeros(M, rowb, dtype=torch.uint8, device=dev)
+    y = Fn.linear(M, H, L.pk(H), w_packed=True, a1=x, k1=H, bias=b, act=Fn.ACT_RELU, drop_p=0.2, seed=77, mask_bits_out=bits)
+    got = bits.cpu().numpy()
+    pos = (y > 0).cpu().numpy()
+    n = np.arange(H)
+    blk, t, h, e = n // 304, (n % 304) // 16, ((n % 304) % 16) // 8, n % 8
+    dec = (got[:, blk * 40 + h * 20 + t] >> e) & 1
+    assert np.array_equal(dec.astype(bool), pos)
+    dy = torch.randn(M, H, device=dev)
+    dz1, dz2 = torch.empty(M, H, device=dev), torch.empty(M, H, device=dev)
+    cw = torch.rand(M, device=dev)
+    o1, p1 = Fn.linear(M, H, L.pk_t(0, H), w_packed=True, a1=dy, k1=H, a_mask=y, mask_scale=1.25, dz_out=dz1, colsum_w=cw)
+    o2, p2 = Fn.linear(M, H, L.pk_t(0, H), w_packed=True, a1=dy, k1=H, a_mask_bits=bits, mask_scale=1.25, dz_out=dz2, colsum_w=cw)
+    assert torch.equal(o1, o2) and torch.equal(dz1, dz2) and torch.equal(p1, p2)
