@@ -329,3 +329,36 @@ def test_gather_sum_masked_equals_relu_backward_then_gather(H, K):
     assert torch.equal(got, ref)
     want = np.where(idx[..., None] >= 0, np.where(mask.cpu().numpy() > 0, src.cpu().numpy() * np.float32(1.0 / 0.9), 0)[np.maximum(idx, 0)], 0).sum(1)
     close(got, want, what="masked gather")
+
+
+@pytest.mark.parametrize("H,F,p", [(300, 1, 0.1), (300, 0, 0.0), (32, 1, 0.3), (30, 1, 0.2)])
+def test_segment_mean_backward_is_the_adjoint_with_the_forward_dropout_stream(H, F, p):
+    """Readout (models/mpn.py:224-238): dx[a] = dout[mol(a)] / size * keep / (1 - p), keep taken from the SAME counter-based
+    stream element (m * (H + F) + c) the forward used - the 4-column kernel (H % 4 == 0) and the scalar one."""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(H + F)
+    sizes = rng.integers(1, 9, size=37)
+    M, nA = len(sizes), int(sizes.sum()) + 1                         # atom 0 is the padding atom (no molecule)
+    starts = np.concatenate([[1], 1 + np.cumsum(sizes)[:-1]])
+    a_scope = np.stack([starts, sizes], 1).astype(np.int32)
+    atom2mol = np.full(nA, -1, np.int32)
+    for m, (s0, n) in enumerate(a_scope):
+        atom2mol[s0:s0 + n] = m
+    g = SimpleNamespace(a_scope=dev(a_scope), atom2mol=dev(atom2mol), M=M, nA=nA)
+    W = H + F
+    dout = rng.standard_normal((M, W)).astype(np.float32)
+    seed = 0x1234567890ABCDEF
+    got = Fn.segment_mean_bwd(dev(dout), g, H, F, p, seed)
+    keep = dropout_ref.keep_mask(seed, (np.arange(M)[:, None] * W + np.arange(H)[None, :]).astype(np.uint64), p) if p > 0 \
+        else np.ones((M, H), bool)
+    per_mol = (dout[:, :H] / sizes[:, None].astype(np.float32)).astype(np.float32)
+    per_mol = np.where(keep, per_mol * np.float32(1.0 / (1.0 - p)), 0).astype(np.float32) if p > 0 else per_mol
+    want = np.zeros((nA, H), np.float32)
+    want[atom2mol >= 0] = per_mol[atom2mol[atom2mol >= 0]]
+    close(got, want, tol=1e-6, what="segment_mean_bwd")
+    x = rng.standard_normal((nA, H)).astype(np.float32)
+    feat = rng.standard_normal((M, max(F, 1))).astype(np.float32)[:, :F]
+    fwd = Fn.segment_mean_fwd(dev(x), g, H, dev(feat) if F else None, F, p, seed)
+    lhs = float((fwd[:, :H].double().cpu() * torch.as_tensor(dout[:, :H]).double()).sum())
+    rhs = float((torch.as_tensor(x).double() * got.double().cpu()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * (1 + abs(lhs))                  # <fwd(x), dout> == <x, bwd(dout)>
