@@ -175,7 +175,7 @@ def weighted_colsum(x, w, H: int, out, accumulate: bool):
 def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub_idx=None, a2=None, k2=0, a_mask=None,
            mask_scale=1.0, ldw=None, w_packed=False, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0,
            out=None, c_pre=None, dz_out=None, dz_accumulate=False, residual_idx=None, colsum_w=None, mask_bits_out=None,
-           a_mask_bits=None):
+           a_mask_bits=None, want_bits=False):
     """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h).
     colsum_w [M]: also returns the per-row-block partial sums of colsum_w[m] * out[m, :]  ->  (out, partial)."""
     ref = a1 if a1 is not None else a2
@@ -200,14 +200,24 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.c, A.ldc = ptr(out), _ld(out)
     A.c_pre, A.ld_pre = ptr(c_pre), _ld(c_pre)
     A.colsum_w, A.colsum_partial, A.ld_partial = ptr(colsum_w), ptr(partial), _ld(partial)
+    split_w = w.dtype == torch.uint8
+    if want_bits and split_w and mask_bits_out is None:  # the output will be a ReLU / dropout mask of a dX GEMM: keep its signs
+        mask_bits_out = torch.empty(M, int(lib().rr_mask_bits_row_bytes(N)), dtype=torch.uint8, device=out.device)
+        out._rr_bits = mask_bits_out
+    if a_mask is not None and a_mask_bits is None and split_w:
+        a_mask_bits = getattr(a_mask, "_rr_bits", None)  # ... and read them instead of the f32 activation (same values)
     A.mask_bits_out, A.a_mask_bits = ptr(mask_bits_out), ptr(a_mask_bits)    # sign-bit images (split GEMM only)
     nt = 4 if N <= 64 else (10 if N <= 160 else 19)
     if M <= 8192 and not (w.dtype == torch.uint8 or int(w_packed) == 2):
         nt = 4                                          # few rows: 64-column blocks (rr_linear_f32)
     mode = 3 if a_mask_bits is not None else (2 if a_mask is not None else (1 if a1_sub is not None else 0))
     kk = k1 + k2
-    nbytes = 4 * (M * kk * (2 if (a1_sub is not None or a_mask is not None) else 1) + N * kk + M * N *
-                  (1 + (residual is not None) + (c_pre is not None)))
+    two_src = a1_sub is not None or (a_mask is not None and a_mask_bits is None)
+    nbytes = 4 * (M * kk * (2 if two_src else 1) + N * kk + M * N * (1 + (residual is not None) + (c_pre is not None)))
+    if a_mask_bits is not None:
+        nbytes += M * a_mask_bits.shape[1]              # the mask as one bit per element
+    if mask_bits_out is not None:
+        nbytes += M * mask_bits_out.shape[1]
     if dz_out is not None:                              # side output d_input (+)= dZ: one write, one read when accumulating
         nbytes += 4 * M * k1 * (2 if dz_accumulate else 1)
     if int(w_packed) == 2:                              # the symbol rocprofv3 shows: <tiles packed, tiles per WG, mode, waves>
@@ -443,13 +453,13 @@ def mpn_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p
     for it in range(depth - 1):                                                                      # :84
         a_msg = gather_sum(msgs[-1], g.a2b, H)                                                       # :89-90
         new = linear(nB, H, Wh.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=g.b2a, a1_sub=msgs[-1], a1_sub_idx=g.b2revb,
-                     bias=Wh.b, residual=inp, act=ACT_RELU, drop_p=p, seed=_site_seed(seed, it))     # :91-97
+                     bias=Wh.b, residual=inp, act=ACT_RELU, drop_p=p, seed=_site_seed(seed, it), want_bits=True)     # :91-97
         amsgs.append(a_msg)
         msgs.append(new)
     del inp
     a_last = gather_sum(msgs[-1], g.a2b, H)                                                          # :101-102
     h = linear(nA, H, Wo.pk(ATOM_FDIM, H), w_packed=True, a1=g.f_atoms, k1=ATOM_FDIM, a2=a_last, k2=H, bias=Wo.b, act=ACT_RELU, drop_p=p,
-               seed=_site_seed(seed, 1000))                                                          # :103-105
+               seed=_site_seed(seed, 1000), want_bits=True)                                                          # :103-105
     return h, (msgs, amsgs, a_last, h)
 
 
@@ -560,13 +570,13 @@ def mpn_forward_shared(gu, g, bmap, H: int, depth: int, Wi: LinW, Wh: LinW, Wo: 
     for it in range(1, depth - 1):
         a_msg = gather_sum(msgs[-1], g.a2b, H)
         new = linear(nB, H, Wh.pk(H), w_packed=True, a1=a_msg, k1=H, a1_idx=g.b2a, a1_sub=msgs[-1], a1_sub_idx=g.b2revb,
-                     bias=Wh.b, residual=inp_u, residual_idx=bmap, act=ACT_RELU, drop_p=p, seed=_site_seed(seed, it))
+                     bias=Wh.b, residual=inp_u, residual_idx=bmap, act=ACT_RELU, drop_p=p, seed=_site_seed(seed, it), want_bits=True)
         amsgs.append(a_msg)
         msgs.append(new)
     del inp_u
     a_last = gather_sum(msgs[-1], g.a2b, H)
     h = linear(nA, H, Wo.pk(ATOM_FDIM, H), w_packed=True, a1=g.f_atoms, k1=ATOM_FDIM, a2=a_last, k2=H, bias=Wo.b,
-               act=ACT_RELU, drop_p=p, seed=_site_seed(seed, 1000))
+               act=ACT_RELU, drop_p=p, seed=_site_seed(seed, 1000), want_bits=True)
     return h, (msgs, amsgs, a_last, h, (msg0_u, a0_u))
 
 
@@ -637,13 +647,13 @@ def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Opt
         for it in range(depth - 1):                                                      # :199
             a_msg = gather_sum(msgs[-1], g.a2a, H)                                       # :201
             new = linear(nA, H, Wh.pk(H, FBOND), w_packed=True, a1=a_msg, k1=H, a2=fb, k2=FBOND, bias=Wh.b, residual=inp, act=ACT_RELU,
-                         drop_p=p, seed=_site_seed(seed, 2001 + it))                     # :202-213
+                         drop_p=p, seed=_site_seed(seed, 2001 + it), want_bits=True)     # :202-213
             amsgs.append(a_msg)
             msgs.append(new)
         a_last = gather_sum(msgs[-1], g.a2a, H)                                          # :215-216
         hid = linear(nA, H, Wo.pk(Hin, H), w_packed=True, a1=x, k1=Hin, a1_sub=x_sub, a1_sub_idx=x_sub_idx, a2=a_last, k2=H,
                      bias=Wo.b, act=ACT_RELU, drop_p=p,
-                     seed=_site_seed(seed, 3000))                                        # :217-219
+                     seed=_site_seed(seed, 3000), want_bits=True)                        # :217-219
     else:
         hid = msg
     del inp
