@@ -123,6 +123,8 @@ class Runner:
         # the reference's build_optimizer / NoamLR (train/utils.py) through their mirrors; fused Adam = same update, one kernel
         self.opt = build_optimizer(self.model, fused=not args.foreach_adam)
         self.bucket = GradBucket(self.model.parameters())
+        if world > 1:
+            self.bucket.attach()                          # gradients are written straight into the all-reduce buffer
         self.sched = build_lr_scheduler(self.opt, warmup_epochs=2, total_epochs=25, train_data_size=100000,
                                         batch_size=cfg["queries"], init_lr=1e-4, max_lr=1e-3, final_lr=1e-4)
         self.RL = RL

@@ -34,10 +34,45 @@ class GradBucket:
         dev = self.params[0].device if self.params else "cpu"
         dtype = self.params[0].dtype if self.params else torch.float32      # fp32 in production (fp64 in the CPU identity test)
         self.flat = torch.zeros(self.numel, dtype=dtype, device=dev)
-        self._views, off = [], 0
+        self._views, self._where, off = [], {}, 0
         for p in self.params:
             self._views.append(self.flat[off:off + p.numel()].view_as(p))
+            self._where[p.data_ptr()] = (off, p.numel(), tuple(p.shape), p)
             off += p.numel()
+
+    def sink(self, t: torch.Tensor):
+        """A FRESH view of the flat buffer for the gradient of the parameter whose storage `t` is (None: not ours)."""
+        w = self._where.get(t.data_ptr())
+        if w is None or w[1] != t.numel() or t.dtype != self.flat.dtype:
+            return None
+        if w[3].grad is not None:          # a second backward before the optimizer step accumulates: it needs its own buffer
+            return None
+        return self.flat[w[0]:w[0] + w[1]].view(w[2])
+
+    _attached: List["GradBucket"] = []
+
+    @staticmethod
+    def _lookup(t: torch.Tensor):
+        for b in GradBucket._attached:
+            v = b.sink(t)
+            if v is not None:
+                return v
+        return None
+
+    def attach(self) -> "GradBucket":
+        """Let the explicit backward of reactranker_amd.functions write gradients straight into this bucket."""
+        from . import functions as Fn
+        if self not in GradBucket._attached:
+            GradBucket._attached.append(self)
+        Fn.GradSink.lookup = GradBucket._lookup
+        return self
+
+    def detach(self) -> None:
+        from . import functions as Fn
+        if self in GradBucket._attached:
+            GradBucket._attached.remove(self)
+        if not GradBucket._attached:
+            Fn.GradSink.lookup = None
 
     def allreduce(self, local_weight: float = 1.0, group=None) -> None:
         """grad <- sum_ranks(local_weight_r * grad_r).  With equal shards pass 1/world."""
@@ -47,11 +82,19 @@ class GradBucket:
                     if p.grad is not None:
                         p.grad.mul_(local_weight)
             return
-        # pack: one batched cat kernel (missing grads contribute zeros), one collective, one batched copy back
-        missing = [p for p in self.params if p.grad is None]
-        for p in missing:
-            p.grad = torch.zeros_like(p)
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+        # gradients born in the bucket (attach()): nothing to pack or unpack
+        inplace = self in GradBucket._attached and all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self._views))
+        if inplace:
+            for p, v in zip(self.params, self._views):     # a parameter the step did not touch contributes zeros
+                if p.grad is None:
+                    v.zero_()
+                    p.grad = v
+        else:
+            # pack: one batched cat kernel (missing grads contribute zeros), one collective, one batched copy back
+            missing = [p for p in self.params if p.grad is None]
+            for p in missing:
+                p.grad = torch.zeros_like(p)
+            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
         if local_weight != 1.0:
             self.flat.mul_(local_weight)
         if GradBucket.profile and self.flat.is_cuda:
@@ -62,7 +105,8 @@ class GradBucket:
             GradBucket.events.append((e0, e1))
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        torch._foreach_copy_([p.grad for p in self.params], list(self._views))
+        if not inplace:
+            torch._foreach_copy_([p.grad for p in self.params], list(self._views))
 
 
 def loss_weight(kind: str, local_queries: int, global_queries: int, local_cands: int, global_cands: int,

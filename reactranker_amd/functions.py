@@ -390,6 +390,21 @@ def head_bwd(dout, raw, head: int):
 
 
 # =========================================================================== layer 2
+class GradSink:
+    """Where the explicit backward writes parameter gradients.  None: fresh tensors.  dp.GradBucket.attach() registers
+    a lookup (parameter storage -> a fresh view into its flat all-reduce buffer), so the gradients are BORN inside the
+    bucket: no pack / unpack copies around the collective (autograd adopts the returned view as `.grad`)."""
+    lookup = None
+
+
+def _grad_like(t):
+    if GradSink.lookup is not None:
+        v = GradSink.lookup(t)
+        if v is not None:
+            return v
+    return torch.empty_like(t, memory_format=torch.contiguous_format)
+
+
 class SplitGemm:
     """Encoder GEMMs on the bf16 matrix core: every f32 operand is written exactly as three bf16 terms and six
     products are accumulated in f32 (rr_linear_args.w_packed = 2; error at or below the f32 MFMA chain's).
@@ -434,8 +449,8 @@ class LinW:
         return self._t[key]
 
     def grads(self):
-        gw = torch.empty_like(self.w)
-        gb = None if self.b is None else torch.empty_like(self.b)
+        gw = _grad_like(self.w)
+        gb = None if self.b is None else _grad_like(self.b)
         return gw, gb
 
 
@@ -996,8 +1011,8 @@ class ReactionModelFn(torch.autograd.Function):
             order = [0, 2, 4, 6, 8, 10] + list(range(12, len(ctx.param_shapes), 2))     # weights; bias = index + 1
             for gi, wi in enumerate(order):
                 w, b = ctx.param_shapes[wi], ctx.param_shapes[wi + 1]
-                gw = None if w is None else torch.empty_like(w, memory_format=torch.contiguous_format)
-                gb = None if b is None else torch.empty_like(b)
+                gw = None if w is None else _grad_like(w)
+                gb = None if b is None else _grad_like(b)
                 G.w[gi], G.b[gi] = ptr(gw), ptr(gb)
                 grads += [gw, gb]
             check(lib().rr_reaction_backward(C.byref(M), C.byref(S), ptr(dout), C.byref(G), flags, stream()),

@@ -638,3 +638,54 @@ def test_kfold_driver_with_config_object(tmp_path, task_type, save_metric):
     raw_all = np.concatenate([np.asarray(b["targets"]) for b in folds(1)[0]])
     assert abs(st["data_scaler"]["means"] - float(raw_all.mean())) < 1e-4          # statistics of the RAW training targets
     assert abs(st["data_scaler"]["stds"] - float(raw_all.std())) < 1e-4
+
+
+def test_gradients_born_in_the_dp_bucket_are_the_same_gradients():
+    """dp.GradBucket.attach(): the explicit backward writes parameter gradients straight into the flat all-reduce
+    buffer (no pack / unpack around the collective).  Same values as without it, `.grad` aliases the bucket, a second
+    backward before the optimizer step still accumulates correctly, and the single-process all-reduce is the scale."""
+    from reactranker_amd.dp import GradBucket
+    from reactranker_amd import functions as Fn
+    cfg = dict(hidden_size=64, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
+               ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
+    w = synth.seeded_weights(O.model_shapes(64, 3, 3, 3, 1, 1, True), 3)
+    model = make_model(cfg, w, dropout=0.1).train()
+    qb = synth.make_queries(9, 4, [5, 8, 3, 6], atoms_lo=5, atoms_hi=12)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+
+    def run():
+        model.dropout_seed = 5
+        out = model(rb, pb, 0, qb.add_features)
+        RL.MLEloss()(out, qb.scope, torch.tensor(qb.targets), 0).sum().backward()
+
+    for plan in (True, False):
+        Fn.StepPlan.enabled = plan
+        try:
+            model.zero_grad(set_to_none=True)
+            run()
+            ref = {k: (torch.zeros_like(p) if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
+            bucket = GradBucket(model.parameters()).attach()
+            try:
+                model.zero_grad(set_to_none=True)
+                run()
+                lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + bucket.flat.numel() * 4
+                for k, p in model.named_parameters():
+                    if p.grad is None:
+                        continue
+                    assert lo <= p.grad.data_ptr() < hi, k
+                    assert torch.equal(p.grad, ref[k]), k
+                run()                                                 # accumulation: .grad stays in the bucket, values add up
+                for k, p in model.named_parameters():
+                    if p.grad is not None:
+                        assert torch.equal(p.grad, ref[k] + ref[k]), k
+                model.zero_grad(set_to_none=True)
+                run()
+                bucket.allreduce(0.5)
+                for k, p in model.named_parameters():
+                    if p.grad is not None:
+                        assert torch.equal(p.grad, ref[k] * 0.5), k
+            finally:
+                bucket.detach()
+        finally:
+            Fn.StepPlan.enabled = True
+    assert Fn.GradSink.lookup is None
