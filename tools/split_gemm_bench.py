@@ -1,4 +1,6 @@
-"""Split (3 x bf16 term) GEMM vs the f32-MFMA GEMM: error against f64 and time, same inputs."""
+"""Split (three bf16 terms) GEMM next to the exact-f32 MFMA GEMM on the same inputs: error against f64 and time for the
+three operand forms (masked dX + dZ side output + column sums, gathered forward, two-segment forward).
+Usage (GPU box): python tools/split_gemm_bench.py [quick]"""
 import sys, os, ctypes as C, torch
 sys.path.insert(0, os.getcwd())
 from reactranker_amd import functions as Fn
@@ -14,6 +16,14 @@ def pack_split(w, transpose, rows, c0, k1, k2):
     d[0].dst, d[0].split = dst.data_ptr(), 1
     check(lib().rr_pack_weights_f32(d, 1, stream()), "pack")
     return dst
+
+def f32_pack(fn):
+    """the exact-f32 MFMA layout of a weight (LinW packs the bf16-term images by default)"""
+    Fn.SplitGemm.enabled = False
+    try:
+        return fn()
+    finally:
+        Fn.SplitGemm.enabled = True
 
 def t(fn, n=20):
     for _ in range(5): fn()
@@ -36,7 +46,7 @@ for M in ((1000, 4133) if quick else (4133, 138881, 71425)):
     # ---- mode 2: dX = (dy * relu mask) W, dz side output, colsum
     dy = torch.randn(M, H, device=dev); y = torch.relu(torch.randn(M, H, device=dev)); cw = torch.rand(M, device=dev)
     Wt = Fn.LinW(W, None)
-    wp = Wt.pk_t(0, H); ws = pack_split(W, 1, H, 0, H, 0)
+    wp = f32_pack(lambda: Wt.pk_t(0, H)); ws = pack_split(W, 1, H, 0, H, 0)
     o1 = torch.empty(M, H, device=dev); o2 = torch.empty(M, H, device=dev); dz1 = torch.empty(M, H, device=dev); dz2 = torch.empty(M, H, device=dev)
     _, p1 = Fn.linear(M, H, wp, w_packed=1, a1=dy, k1=H, a_mask=y, mask_scale=1.1, out=o1, dz_out=dz1, colsum_w=cw)
     _, p2 = Fn.linear(M, H, ws, w_packed=2, ldw=0, a1=dy, k1=H, a_mask=y, mask_scale=1.1, out=o2, dz_out=dz2, colsum_w=cw)
@@ -53,7 +63,7 @@ for M in ((1000, 4133) if quick else (4133, 138881, 71425)):
     b2a = torch.randint(0, nA, (M,), device=dev, dtype=torch.int32); rev = torch.randint(0, M, (M,), device=dev, dtype=torch.int32)
     b2a[0] = -1; rev[0] = -1
     Wl = Fn.LinW(W, b)
-    wp = Wl.pk(H); ws = pack_split(W, 0, H, 0, H, 0)
+    wp = f32_pack(lambda: Wl.pk(H)); ws = pack_split(W, 0, H, 0, H, 0)
     kw = dict(a1=am, k1=H, a1_idx=b2a, a1_sub=msg, a1_sub_idx=rev, bias=b, residual=inp, act=Fn.ACT_RELU, drop_p=0.1, seed=1234)
     o1 = Fn.linear(M, H, wp, w_packed=1, **kw); o2 = Fn.linear(M, H, ws, w_packed=2, ldw=0, **kw)
     z = torch.zeros(1, device=dev)
@@ -69,7 +79,7 @@ for M in ((1000, 4133) if quick else (4133, 138881, 71425)):
     Wo = torch.randn(H, 133 + H, device=dev) / 20
     fa = torch.zeros(M, 136, device=dev); fa[:, :133] = (torch.rand(M, 133, device=dev) < 0.1).float(); a2 = torch.randn(M, H, device=dev)
     Wl = Fn.LinW(Wo, b)
-    wp = Wl.pk(133, H); ws = pack_split(Wo, 0, H, 0, 133, H)
+    wp = f32_pack(lambda: Wl.pk(133, H)); ws = pack_split(Wo, 0, H, 0, 133, H)
     pre1 = torch.empty(M, H, device=dev); pre2 = torch.empty(M, H, device=dev)
     kw = dict(a1=fa, k1=133, a2=a2, k2=H, bias=b, act=Fn.ACT_RELU)
     o1 = Fn.linear(M, H, wp, w_packed=1, c_pre=pre1, **kw); o2 = Fn.linear(M, H, ws, w_packed=2, ldw=0, c_pre=pre2, **kw)

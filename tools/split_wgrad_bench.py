@@ -1,4 +1,5 @@
-"""Split weight-gradient GEMM vs the f32-MFMA one: error against f64 and time."""
+"""Split weight-gradient GEMM next to the f32-MFMA one: error against f64 and time for the W_h / W_o / W_i / diff-W_h forms.
+Usage (GPU box): python tools/split_wgrad_bench.py [quick]"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 from reactranker_amd import functions as Fn
