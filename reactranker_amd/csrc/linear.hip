@@ -939,7 +939,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       if (mb_on) {
         const uint32_t nib = (stored.x > 0.f ? 1u : 0u) | (stored.y > 0.f ? 2u : 0u) | (stored.z > 0.f ? 4u : 0u) | (stored.w > 0.f ? 8u : 0u);
         const uint32_t other = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, static_cast<int>(nib)));
-        mb[tc >> 2] |= (nib | (other << 4)) << (8 * (tc & 3));
+        if (NT == 19) {
+          mb[tc >> 2] |= (nib | (other << 4)) << (8 * (tc & 3));
+        } else if (row_ok && (fkq & 1) == 0 && (full || tc + 1 < NT)) {       // narrow column blocks: one byte store per tile
+          const int tg = t0 + tc;
+          a.mask_bits_out[m * mask_bits_row(a.N) + (tg / 19) * 40 + (fkq >> 1) * 20 + (tg % 19)] =
+              static_cast<uint8_t>(nib | (other << 4));
+        }
       }
       if (cs_on) {
         f32x4 t = stored * wrow;
@@ -956,7 +962,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       }
     }
   }
-  if (mb_on && row_ok && (fkq & 1) == 0) {
+  if (NT == 19 && mb_on && row_ok && (fkq & 1) == 0) {
     uint32_t* d = reinterpret_cast<uint32_t*>(a.mask_bits_out + m * mask_bits_row(a.N) + blockIdx.y * 40 + (fkq >> 1) * 20);
 #pragma unroll
     for (int i = 0; i < 5; ++i) d[i] = mb[i];
@@ -1895,6 +1901,9 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
     P.t2 = r32(a.k2) / SK;
     if (a.N <= 64) return launch_split<4, 4, 8>(P, s);
     if (a.N <= 160) return launch_split<10, 10, 8>(P, s);
+    // few rows (the distinct reactants of a shared-prefix step: ~2 k bonds): 192-row workgroups would leave most CUs idle,
+    // so the 19 column tiles are cut into blocks of 5 (5 + 5 + 5 + 4) as well - same weight image, same k order
+    if (a.N <= 304 && a.M <= 8192) return launch_split<19, 5, 8>(P, s);
     if (a.N <= 304) return launch_split<19, 19, 12>(P, s);
     return launch_split<38, 19, 12>(P, s);               // two column blocks of 19 tiles (H = 600)
   }

@@ -222,7 +222,10 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
         nbytes += 4 * M * k1 * (2 if dz_accumulate else 1)
     if int(w_packed) == 2:                              # the symbol rocprofv3 shows: <tiles packed, tiles per WG, mode, waves>
         ntp = 38 if N > 304 else nt
-        key = f"linear_split_kernel<{ntp},{nt},{mode},{12 if nt == 19 else 8}>"
+        if nt == 19 and ntp == 19 and M <= 8192:
+            key = f"linear_split_kernel<19,5,{mode},8>"   # few rows: column blocks of 5 tiles (rr_linear_f32)
+        else:
+            key = f"linear_split_kernel<{ntp},{nt},{mode},{12 if nt == 19 else 8}>"
     else:
         key = f"{'linear_fast_kernel' if w_packed else 'linear_kernel'}<{nt},{mode}>"
     with _Timed(key, 2 * M * N * kk, nbytes):
