@@ -849,6 +849,32 @@ class SegmentMeanFn(torch.autograd.Function):
         return segment_mean_bwd(_rowmajor(dout, "grad"), ctx.g, ctx.H, 0, 0.0, 0), None, None
 
 
+class _WorkspacePool:
+    """Workspaces of the step plans (one ~2 GB buffer per step, live from forward to backward).  The steps of an epoch
+    differ in size by a few per cent; asking the caching allocator for a new size every step costs a fresh hipMalloc
+    (~80-180 ms) whenever no cached block fits.  The pool hands a returned buffer to the next step if it is large enough
+    and allocates with 12 % headroom otherwise, so it stops growing after the first steps.  Reuse is stream-ordered like
+    the allocator's own: a buffer comes back after its backward was enqueued, and that backward joins the library's
+    side streams to the caller's stream before it returns."""
+    free: List[torch.Tensor] = []
+
+    @classmethod
+    def take(cls, nbytes: int, device) -> torch.Tensor:
+        best = None
+        for i, t in enumerate(cls.free):
+            if t.device == device and t.numel() >= nbytes and (best is None or t.numel() < cls.free[best].numel()):
+                best = i
+        if best is not None:
+            return cls.free.pop(best)
+        cls.free = [t for t in cls.free if t.device != device]          # too small for this model now: let them go
+        return torch.empty(int(nbytes * 1.125) + 4096, dtype=torch.uint8, device=device)
+
+    @classmethod
+    def give(cls, t: torch.Tensor) -> None:
+        if len(cls.free) < 4:
+            cls.free.append(t)
+
+
 class StepPlan:
     """The whole forward / backward of the model as ONE C-ABI call each (rr_reaction_forward / rr_reaction_backward,
     csrc/plan.hip): the launch sequence below (mpn_forward ... ffn_backward) issued by native code instead of ~140
@@ -948,13 +974,13 @@ class ReactionModelFn(torch.autograd.Function):
             nbytes = int(lib().rr_reaction_workspace_bytes(C.byref(M), C.byref(S)))
             if nbytes == 0:
                 raise RuntimeError("rr_reaction_workspace_bytes rejected the step (inconsistent model / batch shapes)")
-            # steps of an epoch differ in size by a few per cent: round the request up to 256 MiB so that the caching
-            # allocator serves every step from the same few blocks (a fresh hipMalloc of ~2 GB is an ~80 ms step)
-            ws = torch.empty((nbytes + (1 << 28) - 1) >> 28 << 28, dtype=torch.uint8, device=pg.device)
+            ws = _WorkspacePool.take(nbytes, pg.device)
             S.workspace, S.workspace_bytes = C.c_void_p(ws.data_ptr()), nbytes
             flags = StepPlan.flags()                    # the backward must lay the workspace out the same way
             check(lib().rr_reaction_forward(C.byref(M), C.byref(S), flags, stream()), "rr_reaction_forward")
             ctx.plan = (M, S, keep, ws, out, flags)
+            if not any(ctx.needs_input_grad):          # (e.g. under torch.no_grad()) no backward will come for this step
+                _WorkspacePool.give(ws)
             ctx.st = st
             ctx.param_shapes = [None if q is None else q for q in params]
             ctx.present = [q is not None for q in params]
@@ -1023,6 +1049,7 @@ class ReactionModelFn(torch.autograd.Function):
             check(lib().rr_reaction_backward(C.byref(M), C.byref(S), ptr(dout), C.byref(G), flags, stream()),
                   "rr_reaction_backward")
             ctx.plan = "done"
+            _WorkspacePool.give(ws)
             return (None, *grads)
         enc, dif, ffn = ctx.mods
         if ctx.saved is None:
