@@ -853,7 +853,7 @@ class _WorkspacePool:
     """Workspaces of the step plans (one ~2 GB buffer per step, live from forward to backward).  The steps of an epoch
     differ in size by a few per cent; asking the caching allocator for a new size every step costs a fresh hipMalloc
     (~80-180 ms) whenever no cached block fits.  The pool hands a returned buffer to the next step if it is large enough
-    and allocates with 12 % headroom otherwise, so it stops growing after the first steps.  Reuse is stream-ordered like
+    and allocates with 25 % headroom otherwise, so it stops growing after the first steps.  Reuse is stream-ordered like
     the allocator's own: a buffer comes back after its backward was enqueued, and that backward joins the library's
     side streams to the caller's stream before it returns."""
     free: List[torch.Tensor] = []
@@ -867,7 +867,7 @@ class _WorkspacePool:
         if best is not None:
             return cls.free.pop(best)
         cls.free = [t for t in cls.free if t.device != device]          # too small for this model now: let them go
-        return torch.empty(int(nbytes * 1.125) + 4096, dtype=torch.uint8, device=device)
+        return torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
 
     @classmethod
     def give(cls, t: torch.Tensor) -> None:
