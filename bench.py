@@ -581,7 +581,8 @@ def main():
             epoch = dict(epoch_queries_per_s=round(qps_e, 2), ms_per_step=round(e_secs / n * 1e3, 3), distinct_steps=n * world,
                          distinct_steps_per_rank=n,
                          vs_resident=round(qps_e / (world * args.steps * cfg["queries"] / elapsed), 4),
-                         step_ms=step_stats(e_per), shard_files=len(shard_paths),
+                         step_ms=step_stats(e_per), slowest_steps=[[int(i), round(float(e_per[i]), 2)] for i in np.argsort(e_per)[-3:][::-1]],
+                         shard_files=len(shard_paths),
                          shard_gb_per_rank=round(sum(os.path.getsize(p) for p in shard_paths) / 1e9, 3),
                          step_mb=round(rd.max_step_bytes / 1e6, 2), h2d_gb_per_rank=round(pf.bytes_copied / 1e9, 3),
                          consumer_wait_s=round(pf.wait_s, 4), pack_s=round(t_shards, 2),
