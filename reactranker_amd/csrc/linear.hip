@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 
   const int nk = P.t1 + P.t2;
   // operand chunks in flight: two k-steps (slot = step & 1), so a load has two MFMA blocks to land; the weight image one
-  f32x4 ra[NT == NTP ? 2 : 1][2], rs[NT == NTP ? 2 : 1][2];
+  f32x4 ra[WAVES == 12 ? 2 : 1][2], rs[WAVES == 12 ? 2 : 1][2];
   uint32_t rb[2] = {0u, 0u};                           // MODE 3: the 8 mask bits of a step's chunk pair
   u32x4 x0, x1, x2;                                    // the three bf16 terms of the current step's operand
 
@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // one k-step with compile-time slots.  vmcnt retires in issue order: the operand loads of step s+2 are issued AFTER the
   // weight image of step s+1, so "all but the youngest NX" = image landed, step s+1's chunks landed, step s+2's in flight.
   constexpr int NX = MODE == 0 ? 2 : (MODE == 3 ? 3 : 4);   // vector-memory instructions of one issue_x
-  constexpr bool DEEP = NT == NTP;                     // the two-workgroups-per-CU geometry has 128 registers: one step ahead
+  constexpr bool DEEP = WAVES == 12;                   // the 8-wave geometries (several workgroups per CU, <= 128 registers): one step ahead
   auto step = [&](int s, int slot) {
     const bool more = s + 1 < nk, more2 = s + 2 < nk;
     if (more) issue_w(s + 1);
