@@ -34,6 +34,7 @@ import queue
 import struct
 import threading
 import time
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -269,7 +270,7 @@ class StepPrefetcher:
     steps; the copy stream then waits for an event the consumer recorded when it released the slot, so a step's
     buffers are never overwritten while its kernels may still be running."""
 
-    def __init__(self, reader: ShardReader, device, order: Iterable[int], depth: int = 3):
+    def __init__(self, reader: ShardReader, device, order: Iterable[int], depth: int = 3, copy_threads: int = 4):
         if depth < 2:
             raise ValueError("depth >= 2 (one step in use, at least one in flight)")
         self.reader, self.device, self.depth = reader, torch.device(device), depth
@@ -288,6 +289,8 @@ class StepPrefetcher:
         self._stop = False
         self.bytes_copied = 0
         self.wait_s = 0.0
+        self.copy_threads = copy_threads
+        self._copiers = ThreadPoolExecutor(max_workers=max(1, copy_threads), thread_name_prefix="rr-shard-copy")
         self.thread = threading.Thread(target=self._run, name="rr-shard-reader", daemon=True)
         self.thread.start()
 
@@ -302,7 +305,7 @@ class StepPrefetcher:
                     last_copy.synchronize()                      # the pinned buffer's previous H2D has been read out
                 blob = self.reader.blob(i)
                 n = blob.shape[0]
-                np.copyto(self.pinned_np[slot][:n], blob)        # page cache -> pinned staging (numpy drops the GIL)
+                self._stage(self.pinned_np[slot], blob, n)       # page cache -> pinned staging (numpy drops the GIL)
                 with torch.cuda.stream(self.copy_stream):
                     if released is not None:
                         self.copy_stream.wait_event(released)    # the slot's last user's kernels have finished
@@ -315,6 +318,19 @@ class StepPrefetcher:
         except BaseException as e:                               # surfaced to the consumer
             self._err = e
             self.ready.put(None)
+
+    def _stage(self, dst: np.ndarray, src: np.ndarray, n: int) -> None:
+        """One step blob (~55 MB) into its pinned slot, cut into a few pieces copied in parallel: a single memcpy thread
+        moves ~10 GB/s, i.e. one blob per ~5.5 ms - the training step's own duration - so one thread alone leaves the
+        input pipeline no margin."""
+        parts = self.copy_threads
+        if parts <= 1 or n < (8 << 20):
+            np.copyto(dst[:n], src[:n])
+            return
+        step = _align((n + parts - 1) // parts, BLOB_ALIGN)
+        futs = [self._copiers.submit(np.copyto, dst[a:min(a + step, n)], src[a:min(a + step, n)]) for a in range(0, n, step)]
+        for f in futs:
+            f.result()
 
     def _views(self, slot: int, i: int) -> Dict[str, torch.Tensor]:
         return _typed_views(self.dev[slot], ShardReader.toc(self.reader.blob(i)))
@@ -359,6 +375,7 @@ class StepPrefetcher:
         for s in range(self.depth):
             self.free.put((s, None, None))
         self.thread.join(timeout=5)
+        self._copiers.shutdown(wait=False)
 
 
 def load_step(reader: ShardReader, i: int, device) -> dict:
