@@ -45,6 +45,7 @@ const char* rr_strerror(int status);
 int rr_version(void);               /* ABI version, bumped on any signature change */
 /* sizeof(rr_linear_args) / sizeof(rr_wgrad_args) as compiled, so a binding can verify its struct layout. */
 void rr_abi_struct_sizes(size_t* linear_args, size_t* wgrad_args);
+size_t rr_abi_gather_epi_size(void);   /* sizeof(rr_gather_epi) as compiled */
 
 /* ------------------------------------------------------------------ gathers -------- */
 
@@ -75,6 +76,34 @@ int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src,
 int rr_gather_sum_masked_f32(const float* src, const float* mask, int64_t n_src, int64_t ld_src,
                              const int32_t* idx, int64_t n_out, int K, int H, float scale,
                              float* out, int64_t ld_out, rr_stream_t stream);
+
+/* Gather-sum with a fused epilogue - the form the backward chain uses (ABI revision 4):
+ *   out[r, :] = M_r( sum_{k<K, idx[r*K+k] >= 0} src[idx[r*K+k], :] )  +  sum_{j<n_adds} adds[j][r, :]
+ *   M_r(g)[c] = g[c]                                   without a mask
+ *             = (mask[r, c] > 0) ? g[c] * mask_scale : 0   with `mask` ([n_out, ld_mask] f32) or `mask_bits` (the sign-bit
+ *               image rr_linear_args.mask_bits_out wrote for that activation: rr_mask_bits_row_bytes(H) bytes per row;
+ *               preferred when both are given - 1/32 of the bytes)
+ * The adjoint of a message-passing layer never needs the gathered gradient as such: d message is consumed masked by the
+ * ReLU / dropout pattern of the layer below (dZ = d message * (y > 0) / (1 - p), models/mpn.py:94-97) and the gradient of
+ * the residual `input` (:94) is the sum of every iteration's dZ.  With the mask and the sum applied here, by the HBM-bound
+ * kernel that produces the gradient, the dX GEMM downstream reads dZ as a plain operand (no mask, no dZ side output
+ * written from inside its k-loop) and rr_relu_bwd_sum_f32's extra pass disappears.  The addends are summed in order
+ * starting from zero and the masked gather is added last - the order of rr_relu_bwd_sum_f32 - so the result equals the
+ * separate-kernel sequence bit for bit.  row0_partial (may be NULL) as in rr_gather_sum_padrow_f32; the epilogue applies
+ * to row 0 as well.  Requires H % 4 == 0 and 16-byte aligned rows everywhere (RR_ERR_ALIGN otherwise); `epi` is a HOST
+ * struct of device pointers. */
+#define RR_MAX_GATHER_ADDS 15
+typedef struct rr_gather_epi {
+  const float* mask;        int64_t ld_mask;
+  const uint8_t* mask_bits;
+  float mask_scale;
+  int n_adds;               int64_t ld_add;      /* every addend is [n_out, ld_add] */
+  const float* adds[RR_MAX_GATHER_ADDS];
+} rr_gather_epi;
+int rr_gather_sum_epi_f32(const float* src, int64_t n_src, int64_t ld_src,
+                          const int32_t* idx, int64_t n_out, int K, int H,
+                          const float* row0_partial, int64_t n_partial, int64_t ld_partial,
+                          const rr_gather_epi* epi, float* out, int64_t ld_out, rr_stream_t stream);
 
 int rr_gather_sum_csr_f32(const float* src, int64_t n_src, int64_t ld_src,
                           const int32_t* offsets, const int32_t* idx, int64_t n_out, int H,
@@ -245,7 +274,7 @@ int rr_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out
 int rr_relu_bwd_f32(const float* dy, const float* y, float scale, float* dz, float* acc,
                     int64_t n, rr_stream_t stream);
 
-/* out = sum_{k<n_adds} adds[k] + dy * (y > 0) * scale.  `adds` is a HOST array of n_adds (<= 8) device pointers.
+/* out = sum_{k<n_adds} adds[k] + dy * (y > 0) * scale.  `adds` is a HOST array of n_adds (<= 15) device pointers.
  * The gradient of a residual read by several layers: `input` of models/mpn.py:80 enters every message-passing
  * iteration (:94), so d input = sum_it dZ_it + relu'(input) * d message_0 - formed in one pass over memory from
  * the per-iteration dZ buffers the input-gradient GEMMs write (rr_linear_args.dz_out). */
@@ -285,6 +314,15 @@ int rr_segment_mean_bwd_f32(const float* dout, int64_t ld_dout, const int32_t* a
                             const int32_t* atom2mol, int64_t n_atoms, int H, int F,
                             float drop_p, uint64_t drop_seed,
                             float* dx, int64_t ldx, rr_stream_t stream);
+
+/* The same followed by the ReLU / dropout backward of the layer that produced the readout's input:
+ *   dx[a, c] = (mask[a, c] > 0) ? dx[a, c] * mask_scale : 0      (mask / mask_bits as in rr_gather_epi; one of them required)
+ * so the two dX GEMMs of W_o's column blocks (models/mpn.py:217-219) read a plain operand.  H % 4 == 0 and aligned rows. */
+int rr_segment_mean_bwd_masked_f32(const float* dout, int64_t ld_dout, const int32_t* a_scope,
+                                   const int32_t* atom2mol, int64_t n_atoms, int H, int F,
+                                   float drop_p, uint64_t drop_seed,
+                                   const float* mask, int64_t ld_mask, const uint8_t* mask_bits, float mask_scale,
+                                   float* dx, int64_t ldx, rr_stream_t stream);
 
 /* ------------------------------------------------------------------ ranking losses - */
 /* Lists are described by seg_off[Q+1] (prefix sums of the reference's `scope` list);

@@ -64,6 +64,16 @@ class WgradArgs(C.Structure):
     ]
 
 
+RR_MAX_GATHER_ADDS = 15
+
+
+class GatherEpi(C.Structure):
+    _fields_ = [
+        ("mask", c_f32p), ("ld_mask", i64), ("mask_bits", C.c_void_p), ("mask_scale", f32),
+        ("n_adds", i32), ("ld_add", i64), ("adds", C.c_void_p * RR_MAX_GATHER_ADDS),
+    ]
+
+
 RR_MAX_FFN = 8
 RR_G_FFN0 = 6
 RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
@@ -115,6 +125,11 @@ _SIGS = {
     "rr_version": (i32, []),
     "rr_abi_struct_sizes": (None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rr_gather_sum_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, c_stream]),
+    "rr_abi_gather_epi_size": (C.c_size_t, []),
+    "rr_gather_sum_epi_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, C.POINTER(GatherEpi), c_f32p, i64,
+                                    c_stream]),
+    "rr_segment_mean_bwd_masked_f32": (i32, [c_f32p, i64, c_i32p, c_i32p, i64, i32, i32, f32, u64, c_f32p, i64, C.c_void_p, f32,
+                                             c_f32p, i64, c_stream]),
     "rr_gather_sum_masked_f32": (i32, [c_f32p, c_f32p, i64, i64, c_i32p, i64, i32, i32, f32, c_f32p, i64, c_stream]),
     "rr_gather_sum_csr_f32": (i32, [c_f32p, i64, i64, c_i32p, c_i32p, i64, i32, c_f32p, i64, c_stream]),
     "rr_build_fbonds_f32": (i32, [c_f32p, i64, i64, i32, c_i32p, c_f32p, i64, i32, i64, c_f32p, i64, c_stream]),
@@ -175,7 +190,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -198,7 +213,7 @@ def lib():
             raise RuntimeError(f"reactranker_amd: ABI version mismatch ({l.rr_version()} != {ABI_VERSION}); rebuild")
         sl, sw = C.c_size_t(), C.c_size_t()
         l.rr_abi_struct_sizes(C.byref(sl), C.byref(sw))
-        if sl.value != C.sizeof(LinearArgs) or sw.value != C.sizeof(WgradArgs):
+        if sl.value != C.sizeof(LinearArgs) or sw.value != C.sizeof(WgradArgs) or l.rr_abi_gather_epi_size() != C.sizeof(GatherEpi):
             raise RuntimeError("reactranker_amd: ctypes struct layout differs from the compiled header")
         sz = [C.c_size_t() for _ in range(4)]
         l.rr_abi_plan_struct_sizes(*[C.byref(x) for x in sz])

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__
 // out = sum_k adds[k] + (y > 0 ? dy * scale : 0): the gradient of a residual that several layers read
 // (d_inp = sum over the message-passing iterations of dZ_it, plus the ReLU-backward of the first layer) in
 // ONE pass over memory instead of a read-modify-write per iteration.
-constexpr int RR_MAX_ADDS = 8;
+constexpr int RR_MAX_ADDS = 15;   // message-passing depth of a step plan (MAXD = 16) minus one: every per-iteration dZ in ONE pass
 struct AddPtrs {
   const float* p[RR_MAX_ADDS];
   int n;
@@ -185,6 +185,8 @@ const char* rr_strerror(int status) {
 }
 
 int rr_version(void) { return RR_ABI_VERSION; }
+
+size_t rr_abi_gather_epi_size(void) { return sizeof(rr_gather_epi); }
 
 void rr_abi_struct_sizes(size_t* linear_args, size_t* wgrad_args) {
   if (linear_args) *linear_args = sizeof(rr_linear_args);

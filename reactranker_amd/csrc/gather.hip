@@ -131,6 +131,108 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------ gather-sum with a fused epilogue
+// out[r] = mask_r (.) (sum_k src[idx[r,k]]) * scale  +  sum_j adds[j][r]
+// The backward chain never needs a gathered gradient as such: d message of one layer is consumed masked by the ReLU /
+// dropout pattern of the layer below (dZ = d message * (y > 0) / (1 - p)), and the gradient of the residual `input`
+// (models/mpn.py:94) is the sum of every iteration's dZ.  Both used to be separate passes over [rows, H] tensors - the mask
+// in the operand loader of the next dX GEMM plus a dZ side output written from inside its k-loop, the sum in
+// rr_relu_bwd_sum_f32.  Here they ride on the HBM-bound gather that produces the gradient: the GEMMs downstream read dZ
+// as a plain operand (no mask, no stores inside their k-loop) and the residual's gradient needs no pass of its own.
+// Same products in the same order as the kernels this replaces, so results are bit-identical to that sequence.
+constexpr int GMAX = RR_MAX_GATHER_ADDS;
+struct GatherEpi {
+  const float* mask;   int64_t ld_mask;
+  const uint8_t* bits; int64_t bits_row;
+  float scale;
+  int n_adds;          int64_t ld_add;
+  const float* adds[GMAX];
+};
+
+// the 4 sign bits of columns c .. c+3 (c % 4 == 0) of row r in a rr_linear_args.mask_bits_out image
+__device__ inline uint32_t epi_nibble(const uint8_t* bits, int64_t bits_row, int64_t r, int c) {
+  const int blk = c / 304, cc = c - blk * 304;
+  const uint32_t b = bits[r * bits_row + blk * 40 + ((cc & 15) >> 3) * 20 + (cc >> 4)];
+  return (b >> (cc & 4)) & 0xFu;
+}
+
+// NADD >= 0: that many addends, unrolled (their loads fly with the gather's); NADD < 0: E.n_adds at run time
+template <int NADD>
+__device__ inline f32x4 epi_apply(const GatherEpi& E, int64_t r, int c, f32x4 g) {
+  f32x4 v = g;
+  if (E.bits != nullptr) {
+    const uint32_t nib = epi_nibble(E.bits, E.bits_row, r, c);
+    v.x = (nib & 1u) ? g.x * E.scale : 0.f; v.y = (nib & 2u) ? g.y * E.scale : 0.f;
+    v.z = (nib & 4u) ? g.z * E.scale : 0.f; v.w = (nib & 8u) ? g.w * E.scale : 0.f;
+  } else if (E.mask != nullptr) {
+    const f32x4 m = ld<4>(E.mask + r * E.ld_mask + c);
+    v.x = m.x > 0.f ? g.x * E.scale : 0.f; v.y = m.y > 0.f ? g.y * E.scale : 0.f;
+    v.z = m.z > 0.f ? g.z * E.scale : 0.f; v.w = m.w > 0.f ? g.w * E.scale : 0.f;
+  }
+  if (NADD == 0) return v;
+  f32x4 s = f32x4(0.f);                               // fixed order: ((0 + add_0) + add_1) + ... , then + v (rr_relu_bwd_sum_f32's)
+  if (NADD > 0) {
+#pragma unroll
+    for (int j = 0; j < (NADD > 0 ? NADD : 1); ++j) s = s + ld<4>(E.adds[j] + r * E.ld_add + c);
+  } else {
+    for (int j = 0; j < E.n_adds; ++j) s = s + ld<4>(E.adds[j] + r * E.ld_add + c);
+  }
+  return s + v;
+}
+
+template <int NADD>
+__global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                             const int32_t* __restrict__ idx, int64_t n_out, int K, int HV,
+                                                             float* __restrict__ out, int64_t ld_out,
+                                                             const float* __restrict__ row0_partial, int64_t n_partial,
+                                                             int64_t ld_partial, const GatherEpi E) {
+  using V = f32x4;
+  const int64_t total = n_out * HV;
+  const int gblocks = row0_partial ? static_cast<int>(gridDim.x) - HV : static_cast<int>(gridDim.x);
+  if (row0_partial != nullptr && static_cast<int>(blockIdx.x) >= gblocks) {      // padding-row reduction, see gather_sum_kernel
+    __shared__ float red[256 * 4];
+    const int c = (static_cast<int>(blockIdx.x) - gblocks) * 4;
+    V a0 = V(0.f), a1 = V(0.f);
+    int64_t i = threadIdx.x;
+    for (; i + 256 < n_partial; i += 512) {
+      a0 = a0 + ld<4>(row0_partial + i * ld_partial + c);
+      a1 = a1 + ld<4>(row0_partial + (i + 256) * ld_partial + c);
+    }
+    if (i < n_partial) a0 = a0 + ld<4>(row0_partial + i * ld_partial + c);
+    st<4>(&red[threadIdx.x * 4], a0 + a1);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      V v = (ld<4>(&red[threadIdx.x * 4]) + ld<4>(&red[(threadIdx.x + 64) * 4])) +
+            (ld<4>(&red[(threadIdx.x + 128) * 4]) + ld<4>(&red[(threadIdx.x + 192) * 4]));
+      v.x = rr_wave_sum(v.x); v.y = rr_wave_sum(v.y); v.z = rr_wave_sum(v.z); v.w = rr_wave_sum(v.w);
+      if (threadIdx.x == 0) st<4>(out + c, epi_apply<NADD>(E, 0, c, v));
+    }
+    return;
+  }
+  const int64_t stride = static_cast<int64_t>(gblocks) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / HV;
+    const int c = static_cast<int>(e - r * HV) * 4;
+    if (r == 0 && row0_partial != nullptr) continue;
+    const int32_t* ir = idx + r * K;
+    V acc = V(0.0f);
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {
+      const int32_t j0 = ir[k], j1 = ir[k + 1], j2 = ir[k + 2], j3 = ir[k + 3];
+      const V v0 = ld<4>(j0 >= 0 ? src + j0 * ld_src + c : gather_zero);
+      const V v1 = ld<4>(j1 >= 0 ? src + j1 * ld_src + c : gather_zero);
+      const V v2 = ld<4>(j2 >= 0 ? src + j2 * ld_src + c : gather_zero);
+      const V v3 = ld<4>(j3 >= 0 ? src + j3 * ld_src + c : gather_zero);
+      acc = (((acc + v0) + v1) + v2) + v3;
+    }
+    for (; k < K; ++k) {
+      const int32_t j = ir[k];
+      acc = acc + ld<4>(j >= 0 ? src + j * ld_src + c : gather_zero);
+    }
+    st<4>(out + r * ld_out + c, epi_apply<NADD>(E, r, c, acc));
+  }
+}
+
 // out[r] = sum_{j in [offs[r], offs[r+1])} src[idx[j]]  (CSR form: rows with arbitrarily many sources - the adjoint of a
 // gather through a GENERIC index table, where no pad width is known without a device->host sync)
 template <int VEC>
@@ -334,7 +436,10 @@ __global__ void __launch_bounds__(256) segment_mean_bwd_vec_kernel(const float* 
                                                                    const int32_t* __restrict__ a_scope,
                                                                    const int32_t* __restrict__ atom2mol, int64_t n_atoms,
                                                                    int HV, int W, uint32_t thr, float keep_scale,
-                                                                   uint64_t seed, float* __restrict__ dx, int64_t ldx) {
+                                                                   uint64_t seed, float* __restrict__ dx, int64_t ldx,
+                                                                   const float* __restrict__ mask, int64_t ld_mask,
+                                                                   const uint8_t* __restrict__ mask_bits, int64_t bits_row,
+                                                                   float mask_scale) {
   const int64_t total = n_atoms * HV;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
@@ -358,6 +463,17 @@ __global__ void __launch_bounds__(256) segment_mean_bwd_vec_kernel(const float* 
           pv[k] = rr_hash_lane(w, static_cast<uint32_t>(i) & 3u) >= thr ? pv[k] * keep_scale : 0.f;
         }
       }
+    }
+    // optional: the ReLU / dropout backward of the layer that produced the readout's input (dZ = dx * (y > 0) * scale),
+    // so the dX GEMMs downstream read a plain operand
+    if (mask_bits != nullptr) {
+      const uint32_t nib = epi_nibble(mask_bits, bits_row, a, c);
+      v.x = (nib & 1u) ? v.x * mask_scale : 0.f; v.y = (nib & 2u) ? v.y * mask_scale : 0.f;
+      v.z = (nib & 4u) ? v.z * mask_scale : 0.f; v.w = (nib & 8u) ? v.w * mask_scale : 0.f;
+    } else if (mask != nullptr) {
+      const float4 m = *reinterpret_cast<const float4*>(mask + a * ld_mask + c);
+      v.x = m.x > 0.f ? v.x * mask_scale : 0.f; v.y = m.y > 0.f ? v.y * mask_scale : 0.f;
+      v.z = m.z > 0.f ? v.z * mask_scale : 0.f; v.w = m.w > 0.f ? v.w * mask_scale : 0.f;
     }
     *reinterpret_cast<float4*>(dx + a * ldx + c) = v;
   }
@@ -400,6 +516,51 @@ int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src, co
     gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256) + H, 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out,
                                                                          row0_partial, n_partial, ld_partial);
   }
+  return rr_launch_status();
+}
+
+int rr_gather_sum_epi_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K, int H,
+                          const float* row0_partial, int64_t n_partial, int64_t ld_partial, const rr_gather_epi* epi,
+                          float* out, int64_t ld_out, rr_stream_t stream) {
+  RR_CHECK_ARG(src && idx && out && epi && n_src >= 0 && n_out >= 1 && K >= 1 && H >= 1 && ld_src >= H && ld_out >= H);
+  RR_CHECK_ARG(!row0_partial || (n_partial >= 0 && ld_partial >= H));
+  RR_CHECK_ARG(epi->n_adds >= 0 && epi->n_adds <= RR_MAX_GATHER_ADDS && (epi->n_adds == 0 || epi->ld_add >= H));
+  RR_CHECK_ARG(!epi->mask || epi->ld_mask >= H);
+  // the fused form exists for the straight-line geometry only (what the packer and the step plans produce)
+  bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(out);
+  if (row0_partial) vec = vec && (ld_partial % 4 == 0) && rr_aligned16(row0_partial);
+  if (epi->mask && !epi->mask_bits) vec = vec && (epi->ld_mask % 4 == 0) && rr_aligned16(epi->mask);
+  GatherEpi E;
+  E.mask = epi->mask_bits ? nullptr : epi->mask;
+  E.ld_mask = epi->ld_mask;
+  E.bits = epi->mask_bits;
+  E.bits_row = rr_mask_bits_row_bytes(H);
+  E.scale = epi->mask_scale;
+  E.n_adds = epi->n_adds;
+  E.ld_add = epi->ld_add;
+  for (int j = 0; j < GMAX; ++j) {
+    E.adds[j] = j < epi->n_adds ? epi->adds[j] : nullptr;
+    if (j < epi->n_adds) {
+      RR_CHECK_ARG(epi->adds[j]);
+      vec = vec && (epi->ld_add % 4 == 0) && rr_aligned16(epi->adds[j]);
+    }
+  }
+  if (!vec) return RR_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HV = H / 4;
+  const int grid = rr_grid_for(n_out * HV, 256) + (row0_partial ? HV : 0);
+#define RR_EPI_LAUNCH(NADD)                                                                                          \
+  gather_sum_epi_kernel<NADD><<<grid, 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out, row0_partial, n_partial, \
+                                                   ld_partial, E)
+  switch (epi->n_adds) {
+    case 0: RR_EPI_LAUNCH(0); break;
+    case 1: RR_EPI_LAUNCH(1); break;
+    case 2: RR_EPI_LAUNCH(2); break;
+    case 3: RR_EPI_LAUNCH(3); break;
+    case 5: RR_EPI_LAUNCH(5); break;
+    default: RR_EPI_LAUNCH(-1); break;
+  }
+#undef RR_EPI_LAUNCH
   return rr_launch_status();
 }
 
@@ -533,6 +694,22 @@ int rr_segment_mean_fwd_f32(const float* x, int64_t ldx, const int32_t* a_scope,
   return rr_launch_status();
 }
 
+int rr_segment_mean_bwd_masked_f32(const float* dout, int64_t ld_dout, const int32_t* a_scope, const int32_t* atom2mol,
+                                   int64_t n_atoms, int H, int F, float drop_p, uint64_t drop_seed, const float* mask,
+                                   int64_t ld_mask, const uint8_t* mask_bits, float mask_scale, float* dx, int64_t ldx,
+                                   rr_stream_t stream) {
+  RR_CHECK_ARG(dout && a_scope && atom2mol && dx && n_atoms >= 0 && H >= 1 && F >= 0 && ld_dout >= H && ldx >= H);
+  RR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  RR_CHECK_ARG((mask || mask_bits) && (!mask || ld_mask >= H));
+  if (n_atoms == 0) return RR_OK;
+  if (!(H % 4 == 0 && ldx % 4 == 0 && rr_aligned16(dx))) return RR_ERR_ALIGN;
+  if (!mask_bits && !(ld_mask % 4 == 0 && rr_aligned16(mask))) return RR_ERR_ALIGN;
+  segment_mean_bwd_vec_kernel<<<rr_grid_for(n_atoms * (H / 4), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      dout, ld_dout, a_scope, atom2mol, n_atoms, H / 4, H + F, rr_drop_threshold(drop_p), 1.0f / (1.0f - drop_p), drop_seed,
+      dx, ldx, mask_bits ? nullptr : mask, ld_mask, mask_bits, rr_mask_bits_row_bytes(H), mask_scale);
+  return rr_launch_status();
+}
+
 int rr_segment_mean_bwd_f32(const float* dout, int64_t ld_dout, const int32_t* a_scope, const int32_t* atom2mol,
                             int64_t n_atoms, int H, int F, float drop_p, uint64_t drop_seed, float* dx, int64_t ldx,
                             rr_stream_t stream) {
@@ -543,7 +720,8 @@ int rr_segment_mean_bwd_f32(const float* dout, int64_t ld_dout, const int32_t* a
   const uint32_t thr = rr_drop_threshold(drop_p);
   if (H % 4 == 0 && ldx % 4 == 0 && rr_aligned16(dx)) {
     segment_mean_bwd_vec_kernel<<<rr_grid_for(n_atoms * (H / 4), 256), 256, 0, s>>>(
-        dout, ld_dout, a_scope, atom2mol, n_atoms, H / 4, H + F, thr, 1.0f / (1.0f - drop_p), drop_seed, dx, ldx);
+        dout, ld_dout, a_scope, atom2mol, n_atoms, H / 4, H + F, thr, 1.0f / (1.0f - drop_p), drop_seed, dx, ldx,
+        nullptr, 0, nullptr, 0, 1.0f);
   } else {
     segment_mean_bwd_kernel<<<rr_grid_for(n_atoms * H, 256), 256, 0, s>>>(dout, ld_dout, a_scope, atom2mol, n_atoms, H,
                                                                           F, thr, 1.0f / (1.0f - drop_p), drop_seed, dx,

@@ -20,6 +20,7 @@
 // f32 MFMA is bit-for-bit an fmaf chain (no reduced precision anywhere); results differ
 // from the CPU reference only by summation order.
 #include "rr_common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -1807,12 +1808,16 @@ inline bool vec_ok(const float* p, int64_t ld) { return p && rr_aligned16(p) && 
 template <int NTP, int NT, int MODE, int WAVES>
 int launch_split_one(const LinearParams& P, hipStream_t s) {
   constexpr int smem = 2 * NT * 3 * 1024 + 16 * NT * 4;
-  static bool configured = false;                      // > 64 KiB of LDS has to be asked for once per kernel
-  if (!configured) {
+  // > 64 KiB of LDS has to be asked for once per kernel AND per device (the attribute lives with the device's code
+  // object); atomics because two host threads may launch the same instantiation at once (setting it twice is harmless)
+  static std::atomic<uint64_t> configured{0};          // bit d: done on device d (devices >= 64 set it every launch)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return RR_ERR_LAUNCH;
+  if (dev < 0 || dev >= 64 || !((configured.load(std::memory_order_acquire) >> dev) & 1u)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NTP, NT, MODE, WAVES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return RR_ERR_LAUNCH;
-    configured = true;
+    if (dev >= 0 && dev < 64) configured.fetch_or(uint64_t(1) << dev, std::memory_order_release);
   }
   const dim3 grid(static_cast<unsigned>((P.a.M + 16 * WAVES - 1) / (16 * WAVES)), static_cast<unsigned>((NTP + NT - 1) / NT));
   linear_split_kernel<NTP, NT, MODE, WAVES><<<grid, 64 * WAVES, smem, s>>>(P);

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "rr_common.h"
 
 namespace {
@@ -46,10 +48,12 @@ struct Streams {
 // per-device side / aux streams (created once; non-blocking so they never synchronise with the null stream)
 struct DevStreams { bool init; hipStream_t side, aux; };
 DevStreams g_streams[64];
+std::mutex g_streams_mu;             // two host threads may issue their first plan at the same time
 
 int get_streams(hipStream_t main, Streams* s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return RR_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lock(g_streams_mu);
   DevStreams& d = g_streams[dev];
   if (!d.init) {
     if (hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking) != hipSuccess) return RR_ERR_LAUNCH;
@@ -154,6 +158,21 @@ void gather_sum(Ctx& c, const float* src, int64_t n_src, int64_t ld_src, const i
   else RR_TRY(c, rr_gather_sum_f32(src, n_src, ld_src, idx, n_out, K, H, out, ld_out, st));
 }
 
+// gather-sum whose epilogue applies the ReLU / dropout mask of the activation `y` (sign bits when a split GEMM wrote
+// them, the f32 tensor otherwise; y == nullptr: no mask) and adds `n_adds` row-aligned tensors (rr_gather_sum_epi_f32)
+void gather_epi(Ctx& c, const float* src, int64_t n_src, const int32_t* idx, int64_t n_out, int K, int H, float* out,
+                hipStream_t st, const float* part, int64_t n_part, bool masked, const float* y, const uint8_t* y_bits,
+                float scale, const float* const* adds, int n_adds) {
+  rr_gather_epi e;
+  memset(&e, 0, sizeof(e));
+  if (masked) { e.mask = y; e.ld_mask = H; e.mask_bits = y_bits; }
+  e.mask_scale = scale;
+  e.n_adds = n_adds;
+  e.ld_add = H;
+  for (int j = 0; j < n_adds; ++j) e.adds[j] = adds[j];
+  RR_TRY(c, rr_gather_sum_epi_f32(src, n_src, H, idx, n_out, K, H, part, n_part, r4(H), &e, out, H, st));
+}
+
 // weight gradient on the side stream: waits for the main stream's work so far (its operands), returns immediately
 void wgrad(Ctx& c, rr_wgrad_args& a) {
   const size_t wb = rr_linear_wgrad_workspace_bytes(a.M, a.N, a.k1 + a.k2);
@@ -225,6 +244,7 @@ void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk
     a.a1 = g.f_bonds; a.lda1 = g.ld_fb; a.k1 = FB;
     set_w(a, pk.enc_wi); a.bias = m.enc_wi.b; a.act = RR_ACT_RELU;
     a.c = S.msgs[0]; a.ldc = H; a.c_pre = inp; a.ld_pre = H;
+    S.bits[0] = mask_bits(c, pk.enc_wi, g.nB, H); a.mask_bits_out = S.bits[0];           // relu'(input) for the backward
     RR_TRY(c, rr_linear_f32(&a, st));                                                   // :80-81
   }
   for (int it = 0; it < depth - 1; ++it) {                                              // :84
@@ -315,6 +335,7 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
     set_w(a, pk.dif_wi); a.bias = m.dif_wi.b; a.act = RR_ACT_RELU;
     a.drop_p = depth == 0 ? p : 0.f; a.drop_seed = site_seed(seed, 2000);              // :221 (depth 0: dropout(message))
     a.c = S.msgs[0]; a.ldc = H; a.c_pre = inp; a.ld_pre = H;
+    S.bits[0] = mask_bits(c, pk.dif_wi, g.nA, H); a.mask_bits_out = S.bits[0];
     RR_TRY(c, rr_linear_f32(&a, st));                                                   // :194-195
   }
   if (depth > 0) {
@@ -435,17 +456,24 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
     w.x1 = g.f_atoms; w.ldx1 = g.ld_fa; w.k1 = m.atom_fdim; w.x2 = S.a_last; w.ldx2 = H; w.k2 = H;
     wgrad(c, w);
   }
-  float* d_msg = c.ar.f(g.nB, H);
-  gather_sum(c, d_a, g.nA, H, g.b2t, g.nB, 1, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nA), r4(H));
+  // From here on every gradient that reaches a layer is produced ALREADY masked by that layer's ReLU / dropout pattern:
+  // the gather that forms d message applies (y > 0) / (1 - p) of the layer below in its epilogue (rr_gather_sum_epi_f32),
+  // so dZ is the gather's output - the dX GEMMs read it as a plain operand and the weight gradients stream it as is -
+  // and the last gather also adds every iteration's dZ: its output is d input (models/mpn.py:94), no pass of its own.
   const float* dzs[MAXD];
   int ndz = 0;
+  float* cur = c.ar.f(g.nB, H);        // dZ of iteration depth-2 (or d input when depth == 1)
+  {
+    const int top = depth - 1;         // the activation whose pattern masks this gradient: msgs[depth-1]
+    gather_epi(c, d_a, g.nA, g.b2t, g.nB, 1, H, cur, st, part, rr_linear_colsum_rows(g.nA), true, S.msgs[top], S.bits[top],
+               top == 0 ? 1.0f : ks, nullptr, 0);
+  }
   for (int it = depth - 2; it >= 0; --it) {
-    float* dz = c.ar.f(g.nB, H);
+    float* dz = cur;
     float* d_min = c.ar.f(g.nB, H);
     float* partb = c.ar.f(rr_linear_colsum_rows(g.nB), r4(H));
     rr_linear_args a = LA(g.nB, H);
-    a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.a_mask_bits = S.bits[it + 1]; a.ld_mask = H; a.mask_scale = ks;
-    a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
+    a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
     a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
     a.c = d_min; a.ldc = H;
     RR_TRY(c, rr_linear_f32(&a, st));
@@ -453,10 +481,13 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
     w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x1_idx = g.b2a; w.x1_sub = S.msgs[it]; w.ldx1_sub = H; w.x1_sub_idx = g.b2revb;
     wgrad(c, w);
     dzs[ndz++] = dz;
-    d_msg = bond_adjoint(c, g, H, d_min, partb, st);
+    // adjoint of the bond message (one gather over b2b_t; row 0 from the GEMM's weighted column sums), masked by msgs[it];
+    // the last one (it == 0: msgs[0] = relu(input), no dropout) adds the dZ of every iteration -> d input
+    cur = c.ar.f(g.nB, H);
+    gather_epi(c, d_min, g.nB, g.b2b_t, g.nB, g.Kb, H, cur, st, partb, rr_linear_colsum_rows(g.nB), true, S.msgs[it], S.bits[it],
+               it == 0 ? 1.0f : ks, dzs, it == 0 ? ndz : 0);
   }
-  float* d_inp = c.ar.f(g.nB, H);
-  RR_TRY(c, rr_relu_bwd_sum_f32(d_msg, S.msgs[0], 1.0f, dzs, ndz, d_inp, g.nB * static_cast<int64_t>(H), st));
+  float* d_inp = cur;
   rr_wgrad_args w = WA(g.nB, H, d_inp, H, G.wi, m.enc_wi.in, G.bi, accumulate);
   w.x1 = g.f_bonds; w.ldx1 = g.ld_fb; w.k1 = m.bond_fdim;
   wgrad(c, w);
@@ -484,18 +515,23 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     w.x1 = g.f_atoms; w.ldx1 = g.ld_fa; w.k1 = m.atom_fdim; w.x2 = S.a_last; w.ldx2 = H; w.k2 = H;
     wgrad(c, w);
   }
+  // per-copy W_h layers (it >= 1): gradients arrive masked from the gather that forms them (see mpn_backward); the one
+  // that reaches the shared prefix stays unmasked - rr_gather_sum_masked_f32 masks it while summing over the copies
   float* d_msg = c.ar.f(g.nB, H);
-  gather_sum(c, d_a, g.nA, H, g.b2t, g.nB, 1, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nA), r4(H));
+  {
+    const bool per_copy = depth - 2 >= 1;
+    gather_epi(c, d_a, g.nA, g.b2t, g.nB, 1, H, d_msg, st, part, rr_linear_colsum_rows(g.nA), per_copy, S.msgs[depth - 1],
+               S.bits[depth - 1], ks, nullptr, 0);
+  }
   float* d_inp_full = nullptr;
   bool have_full = false;            // (flags, not pointer tests: a layout pass hands out null pointers)
   int wh_started = accumulate;
   for (int it = depth - 2; it >= 1; --it) {                                             // per-copy W_h layers
-    float* dz = c.ar.f(g.nB, H);
+    float* dz = d_msg;
     float* d_min = c.ar.f(g.nB, H);
     float* partb = c.ar.f(rr_linear_colsum_rows(g.nB), r4(H));
     rr_linear_args a = LA(g.nB, H);
-    a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.a_mask_bits = S.bits[it + 1]; a.ld_mask = H; a.mask_scale = ks;
-    a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
+    a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
     a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
     a.c = d_min; a.ldc = H;
     RR_TRY(c, rr_linear_f32(&a, st));
@@ -511,7 +547,9 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
       RR_TRY(c, rr_axpby_f32(1.0f, d_inp_full, 1.0f, dz, sum, g.nB * static_cast<int64_t>(H), st));
       d_inp_full = sum;
     }
-    d_msg = bond_adjoint(c, g, H, d_min, partb, st);
+    d_msg = c.ar.f(g.nB, H);
+    gather_epi(c, d_min, g.nB, g.b2b_t, g.nB, g.Kb, H, d_msg, st, partb, rr_linear_colsum_rows(g.nB), it - 1 >= 1, S.msgs[it],
+               S.bits[it], ks, nullptr, 0);
   }
   // ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
   // dz1 of every copy is read once, by the sum over the copies: mask and gather in one pass (no [nB, H] round trip)
@@ -553,17 +591,19 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
   const float ks = 1.0f / (1.0f - p);
   hipStream_t st = c.s.main;
   float* d_hid = c.ar.f(g.nA, H);
-  RR_TRY(c, rr_segment_mean_bwd_f32(dvecs, ld_dvecs, g.a_scope, g.atom2mol, g.nA, H, F, p, out_seed, d_hid, H, st));
   float* d_x = nullptr;
   float* d_inp = nullptr;
   if (depth > 0) {
+    // hid = drop(relu(.)): the readout's adjoint applies that pattern as it writes (dZ of W_o), so both column blocks
+    // of W_o read a plain operand; the message-passing iterations below follow mpn_backward
+    float* dz_o = d_hid;
+    RR_TRY(c, rr_segment_mean_bwd_masked_f32(dvecs, ld_dvecs, g.a_scope, g.atom2mol, g.nA, H, F, p, out_seed, S.hid, H, S.bits_hid,
+                                             ks, dz_o, H, st));
     const Packed wo_x = T.dif_wo_x, wo_a = T.dif_wo_a;
-    float* dz_o = c.ar.f(g.nA, H);
     d_x = c.ar.f(g.nA, H);
     {
       rr_linear_args a = LA(g.nA, H);
-      a.a1 = d_hid; a.lda1 = H; a.k1 = H; a.a_mask = S.hid; a.a_mask_bits = S.bits_hid; a.ld_mask = H; a.mask_scale = ks;
-      a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_x); a.c = d_x; a.ldc = H;
+      a.a1 = dz_o; a.lda1 = H; a.k1 = H; set_w(a, wo_x); a.c = d_x; a.ldc = H;
       RR_TRY(c, rr_linear_f32(&a, st));
     }
     {
@@ -576,23 +616,26 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
     float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
     {
       rr_linear_args a = LA(g.nA, H);
-      a.a1 = d_hid; a.lda1 = H; a.k1 = H; a.a_mask = S.hid; a.a_mask_bits = S.bits_hid; a.ld_mask = H; a.mask_scale = ks;
+      a.a1 = dz_o; a.lda1 = H; a.k1 = H;
       set_w(a, wo_a); a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
       a.c = d_a; a.ldc = H;
       RR_TRY(c, rr_linear_f32(&a, st));
     }
-    float* d_msg = c.ar.f(g.nA, H);
-    gather_sum(c, d_a, g.nA, H, g.a2a_t, g.nA, g.K, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nA), r4(H));
     const float* dzs[MAXD];
     int ndz = 0;
+    float* cur = c.ar.f(g.nA, H);
+    {
+      const int top = depth - 1;
+      gather_epi(c, d_a, g.nA, g.a2a_t, g.nA, g.K, H, cur, st, part, rr_linear_colsum_rows(g.nA), true, S.msgs[top], S.bits[top],
+                 top == 0 ? 1.0f : ks, nullptr, 0);
+    }
     const Packed wh_t = T.dif_wh;
     for (int it = depth - 2; it >= 0; --it) {
-      float* dz = c.ar.f(g.nA, H);
+      float* dz = cur;
       float* d_a2 = c.ar.f(g.nA, H);
       float* part2 = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
       rr_linear_args a = LA(g.nA, H);
-      a.a1 = d_msg; a.lda1 = H; a.k1 = H; a.a_mask = S.msgs[it + 1]; a.a_mask_bits = S.bits[it + 1]; a.ld_mask = H; a.mask_scale = ks;
-      a.dz_out = dz; a.ld_dz = H; set_w(a, wh_t);
+      a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
       a.colsum_w = g.npad; a.colsum_partial = part2; a.ld_partial = r4(H);
       a.c = d_a2; a.ldc = H;
       RR_TRY(c, rr_linear_f32(&a, st));
@@ -600,12 +643,13 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
       w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x2 = g.fb_sum; w.ldx2 = g.ld_fbs; w.k2 = FB;
       wgrad(c, w);
       dzs[ndz++] = dz;
-      d_msg = c.ar.f(g.nA, H);
-      gather_sum(c, d_a2, g.nA, H, g.a2a_t, g.nA, g.K, H, d_msg, H, st, part2, rr_linear_colsum_rows(g.nA), r4(H));
+      cur = c.ar.f(g.nA, H);
+      gather_epi(c, d_a2, g.nA, g.a2a_t, g.nA, g.K, H, cur, st, part2, rr_linear_colsum_rows(g.nA), true, S.msgs[it], S.bits[it],
+                 it == 0 ? 1.0f : ks, dzs, it == 0 ? ndz : 0);
     }
-    d_inp = c.ar.f(g.nA, H);
-    RR_TRY(c, rr_relu_bwd_sum_f32(d_msg, S.msgs[0], 1.0f, dzs, ndz, d_inp, g.nA * static_cast<int64_t>(H), st));
+    d_inp = cur;
   } else {
+    RR_TRY(c, rr_segment_mean_bwd_f32(dvecs, ld_dvecs, g.a_scope, g.atom2mol, g.nA, H, F, p, out_seed, d_hid, H, st));
     d_inp = c.ar.f(g.nA, H);
     RR_TRY(c, rr_relu_bwd_f32(d_hid, S.msgs[0], ks, d_inp, nullptr, g.nA * static_cast<int64_t>(H), st));   // hid = drop(relu(inp))
   }
@@ -720,7 +764,9 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
   // The reactant pass may run on the aux stream beside the product pass (independent chains; their gather kernels are
   // HBM-bound and co-reside with the other chain's one-workgroup-per-CU GEMMs).  Weight gradients of both go to the one
   // side stream in issue order - product pass first - so the accumulation order does not depend on the overlap.
-  const bool fork = c.aux_bwd && c.use_aux;
+  // Only with the side stream: without it the weight gradients launch on c.cur, so the reactant pass on aux would
+  // accumulate into buffers the product pass is still writing on main (no ordering between the two).
+  const bool fork = c.aux_bwd && c.use_aux && c.use_side;
   if (c.launch && fork) c.fail(stream_wait(c.s.aux, main));
   mpn_backward(c, m, s.p, P.pk, wh_t, wo_t, p, P.p, d_diff, 1.0f, E, 0);
   if (fork) c.cur = c.s.aux;

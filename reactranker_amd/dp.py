@@ -83,11 +83,18 @@ class GradBucket:
                         p.grad.mul_(local_weight)
             return
         # gradients born in the bucket (attach()): nothing to pack or unpack
-        inplace = self in GradBucket._attached and all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self._views))
+        born = [p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self._views)]
+        inplace = self in GradBucket._attached and any(born)
         if inplace:
-            for p, v in zip(self.params, self._views):     # a parameter the step did not touch contributes zeros
-                if p.grad is None:
+            # Mixed case: a gradient autograd produced outside the explicit backward (an extra head, a cloned or
+            # non-contiguous gradient) is copied into ITS view only - a `cat(..., out=flat)` over all of them would read
+            # and write the same memory for the ones already living in `flat`.
+            for p, v, b in zip(self.params, self._views, born):
+                if p.grad is None:                         # a parameter the step did not touch contributes zeros
                     v.zero_()
+                    p.grad = v
+                elif not b:
+                    v.copy_(p.grad)
                     p.grad = v
         else:
             # pack: one batched cat kernel (missing grads contribute zeros), one collective, one batched copy back

@@ -93,16 +93,39 @@ def _new(like: torch.Tensor, *shape) -> torch.Tensor:
 
 
 # =========================================================================== layer 1
-def gather_sum(src: torch.Tensor, idx: torch.Tensor, H: int, out: torch.Tensor = None, row0_partial=None) -> torch.Tensor:
+def gather_sum(src: torch.Tensor, idx: torch.Tensor, H: int, out: torch.Tensor = None, row0_partial=None, *, mask=None,
+               mask_scale: float = 1.0, adds=()) -> torch.Tensor:
     """out[r] = sum_k src[idx[r,k]] — index_select_ND + sum(dim=1) (utils.py:176-193; models/mpn.py:89-90).
     row0_partial [n, >=H]: output row 0 (the padding row) is the fixed-order sum of these rows instead — the
-    weighted column sums a dX GEMM wrote next to its output (linear(..., colsum_w=...))."""
+    weighted column sums a dX GEMM wrote next to its output (linear(..., colsum_w=...)).
+    mask / adds: the fused epilogue of rr_gather_sum_epi_f32 — out = (mask > 0 ? out * mask_scale : 0) + sum(adds), i.e.
+    the ReLU / dropout backward of the layer below and the sum over the residual's readers ride on the gather (the
+    mask's sign-bit image is read instead of the f32 tensor when the GEMM that produced it wrote one)."""
     n_out, K = (idx.shape[0], idx.shape[1]) if idx.dim() == 2 else (idx.shape[0], 1)
     if out is None:
         out = _new(src, n_out, H)
-    # algorithmic bytes: every source row once, every output row once, the index table once
-    with _Timed("gather_sum_kernel", 0, 4 * (src.shape[0] * H + n_out * H + n_out * K)):
-        if row0_partial is None:
+    adds = list(adds)
+    epi = mask is not None or len(adds) > 0
+    # algorithmic bytes: every source row once, every output row once, the index table once (+ the epilogue's operands)
+    nbytes = 4 * (src.shape[0] * H + n_out * H + n_out * K)
+    if epi:
+        bits = None if mask is None else getattr(mask, "_rr_bits", None)
+        nbytes += 4 * n_out * H * len(adds) + (0 if mask is None else (n_out * bits.shape[1] if bits is not None else 4 * n_out * H))
+        E = _lib.GatherEpi()
+        if mask is not None:
+            assert mask.shape[0] == n_out
+            E.mask, E.ld_mask, E.mask_bits = ptr(mask), _ld(mask), ptr(bits)
+        E.mask_scale = float(mask_scale)
+        E.n_adds, E.ld_add = len(adds), (_ld(adds[0]) if adds else 0)
+        for j, t in enumerate(adds):
+            assert t.shape[0] == n_out and _ld(t) == E.ld_add
+            E.adds[j] = t.data_ptr()
+    with _Timed("gather_sum_epi_kernel" if epi else "gather_sum_kernel", 0, nbytes):
+        if epi:
+            check(lib().rr_gather_sum_epi_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), n_out, K, H, ptr(row0_partial),
+                                              0 if row0_partial is None else row0_partial.shape[0], _ld(row0_partial),
+                                              C.byref(E), ptr(out), _ld(out), stream()), "rr_gather_sum_epi_f32")
+        elif row0_partial is None:
             check(lib().rr_gather_sum_f32(ptr(src), src.shape[0], _ld(src), ptr(idx), n_out, K, H, ptr(out), _ld(out),
                                           stream()), "rr_gather_sum_f32")
         else:
@@ -332,7 +355,7 @@ def relu_bwd(dy, y, scale: float, dz=None, acc=None, want_dz=True):
     return dz
 
 
-MAX_ADDS = 8
+MAX_ADDS = 15      # = RR_MAX_ADDS (csrc/elementwise.hip): the step plan hands every dZ of a depth <= 16 model to one launch
 
 
 def relu_bwd_sum(dy, y, scale: float, adds):
@@ -371,8 +394,15 @@ def segment_mean_fwd(x, g, H: int, feat, F: int, drop_p: float, seed: int):
     return out
 
 
-def segment_mean_bwd(dout, g, H: int, F: int, drop_p: float, seed: int):
+def segment_mean_bwd(dout, g, H: int, F: int, drop_p: float, seed: int, mask=None, mask_scale: float = 1.0):
+    """mask: also apply the ReLU / dropout backward of the readout's input, dx = (mask > 0) ? dx * mask_scale : 0."""
     dx = _new(dout, g.nA, H)
+    if mask is not None:
+        check(lib().rr_segment_mean_bwd_masked_f32(ptr(dout), _ld(dout), ptr(g.a_scope), ptr(g.atom2mol), g.nA, H, F,
+                                                   float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(mask), _ld(mask),
+                                                   ptr(getattr(mask, "_rr_bits", None)), float(mask_scale), ptr(dx), _ld(dx),
+                                                   stream()), "rr_segment_mean_bwd_masked_f32")
+        return dx
     check(lib().rr_segment_mean_bwd_f32(ptr(dout), _ld(dout), ptr(g.a_scope), ptr(g.atom2mol), g.nA, H, F,
                                         float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(dx), _ld(dx), stream()),
           "rr_segment_mean_bwd_f32")
@@ -466,7 +496,8 @@ def mpn_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p
     nA, nB = g.nA, g.nB
     inp = _new(g.f_bonds, nB, H)
     msg = _new(g.f_bonds, nB, H)
-    linear(nB, H, Wi.pk(FBOND), w_packed=True, a1=g.f_bonds, k1=FBOND, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp)          # :80-81
+    linear(nB, H, Wi.pk(FBOND), w_packed=True, a1=g.f_bonds, k1=FBOND, bias=Wi.b, act=ACT_RELU, out=msg, c_pre=inp,
+           want_bits=True)                                                                           # :80-81
     msgs, amsgs = [msg], []
     for it in range(depth - 1):                                                                      # :84
         a_msg = gather_sum(msgs[-1], g.a2b, H)                                                       # :89-90
@@ -481,13 +512,14 @@ def mpn_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, p
     return h, (msgs, amsgs, a_last, h)
 
 
-def bond_message_adjoint(d_min, g, H: int, partial=None):
+def bond_message_adjoint(d_min, g, H: int, partial=None, *, mask=None, mask_scale: float = 1.0, adds=()):
     """Adjoint of  message = a_message[b2a] - message[b2revb],  a_message = sum_k message[a2b]  (models/mpn.py:89-92):
     d message[b] = sum of d_min over the bonds leaving target(b) except rev(b) - ONE gather-sum over the packer's
     bond-to-bond table (rr_derive_bond_tables) instead of gather-sum + gather-diff; the padding row's adjoint
     (row 0 is read K - deg(a) times by atom a) is the weighted column sum over d_min."""
     if partial is not None:                              # the GEMM that produced d_min already summed npad_b[b] * d_min[b]
-        return gather_sum(d_min, g.b2b_t, H, row0_partial=partial)
+        return gather_sum(d_min, g.b2b_t, H, row0_partial=partial, mask=mask, mask_scale=mask_scale, adds=adds)
+    assert mask is None and not adds
     d_msg = gather_sum(d_min, g.b2b_t, H)
     weighted_colsum(d_min, g.npad_b, H, d_msg[0], accumulate=True)
     return d_msg
@@ -515,53 +547,55 @@ def mpn_backward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: LinW, 
         gWo, gbo = Wo.grads()
         gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
     # atom_hiddens = drop(relu([f_atoms | a_last] W_o^T + b_o))
-    fused = (H % 4 == 0)                                             # ReLU backward fused into the GEMM operand loads
-    # Fused form: the input-gradient GEMM applies the ReLU/dropout mask in its operand loader and writes the masked
-    # gradient dZ as a side output; the weight-gradient GEMM (other stream) then streams dZ as is - it reads no
-    # mask and applies none (one operand stream and 12 staging registers less: -14...-22 % on the bond-level launches).
+    fused = (H % 4 == 0)                                             # ReLU backward fused into producers / operand loads
+    # Fused form, W_o layer: the input-gradient GEMM applies the ReLU/dropout mask in its operand loader (dH has two
+    # consumers with different masks - the product and the reactant encoder) and writes the masked gradient dZ as a side
+    # output; the weight-gradient GEMM (other stream) streams dZ as is.
     if fused:
         dz_o = torch.empty_like(dH)
         # ... and the padding row's adjoint sum_a npad[a] * d_a[a] as per-row-block partial sums (colsum_w)
         d_a, part = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h,
                            mask_scale=sign * ks, dz_out=dz_o, colsum_w=g.npad)
         wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, accumulate=acc0, side=True)
-        # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)]
-        d_msg = gather_sum(d_a, g.b2t, H, row0_partial=part)
+        # a_last[a] = sum_k msg[a2b[a,k]]  ->  d_msg[b] = d_a[target(b)].  From here on every gradient that reaches a layer
+        # is produced ALREADY masked by that layer's ReLU / dropout pattern: the gather that forms d message applies
+        # (y > 0) / (1 - p) of the layer below in its epilogue, so dZ is the gather's output (the dX GEMM reads a plain
+        # operand, the weight gradient streams it as is), and the last gather also adds every iteration's dZ -> d input.
+        top = depth - 1
+        cur = gather_sum(d_a, g.b2t, H, row0_partial=part, mask=msgs[top], mask_scale=(1.0 if top == 0 else ks))
+        dzs = []
+        for it in reversed(range(depth - 1)):
+            dz = cur
+            d_min, part = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H, colsum_w=g.npad_b)
+            wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
+                  accumulate=(acc0 or it != depth - 2), side=True)
+            dzs.append(dz)
+            cur = bond_message_adjoint(d_min, g, H, part, mask=msgs[it], mask_scale=(1.0 if it == 0 else ks),
+                                       adds=(dzs if it == 0 else ()))
+        d_inp = cur                                                  # sum_it dZ_it + relu'(inp) * d msgs[0]  (:94)
+        wgrad(nB, H, d_inp, gWi, dbias=gbi, x1=g.f_bonds, k1=FBOND, accumulate=acc0, side=True)
+        return gWi, gbi, gWh, gbh, gWo, gbo
     else:
         wgrad(nA, H, dH, gWo, dbias=gbo, mask=h, mask_scale=sign * ks, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H,
               accumulate=acc0, side=True)
         d_a = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks)
         d_msg = gather_sum(d_a, g.b2t, H)
         _pad_row_fix(d_msg, d_a, g, H)
+    # H % 4 != 0: separate ReLU-backward passes.  dz is read by the weight-gradient stream, so every iteration gets a fresh
+    # buffer and d_inp accumulates in a buffer that stream never reads before the final W_i launch (which is ordered
+    # after all main-stream writes).
     d_inp = None
-    dzs = []                                                         # fused: one dZ buffer per iteration
     for it in reversed(range(depth - 1)):
         # msgs[it+1] = drop(relu(inp + m_in W_h^T + b_h)),  m_in = amsgs[it][b2a] - msgs[it][b2revb]
-        first = d_inp is None
-        if fused:
-            dz = torch.empty_like(d_msg)                             # fresh: the weight-gradient stream reads it
-            d_min, part = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
-                                 dz_out=dz, colsum_w=g.npad_b)
-            wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
-                  accumulate=(acc0 or it != depth - 2), side=True)
-            dzs.append(dz)
-            d_msg = bond_message_adjoint(d_min, g, H, part)          # fresh buffer: the side stream may still read the old one
-            continue
-        else:
-            # H % 4 != 0: separate ReLU-backward pass.  dz is read by the weight-gradient stream, so every
-            # iteration gets a fresh buffer and d_inp accumulates in a buffer that stream never reads
-            # before the final W_i launch (which is ordered after all main-stream writes).
-            if first:
-                d_inp = torch.zeros_like(d_msg)
-            dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=torch.empty_like(d_msg), acc=d_inp)
-            wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it],
-                  x1_sub_idx=g.b2revb, accumulate=(acc0 or it != depth - 2), side=True)
-            d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
+        if d_inp is None:
+            d_inp = torch.zeros_like(d_msg)
+        dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=torch.empty_like(d_msg), acc=d_inp)
+        wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it],
+              x1_sub_idx=g.b2revb, accumulate=(acc0 or it != depth - 2), side=True)
+        d_min = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
         d_msg = bond_message_adjoint(d_min, g, H)
     # msgs[0] = relu(inp);  d inp = sum_it dZ_it + relu'(inp) * d msgs[0]   (inp is the residual of every iteration, :94)
-    if fused:
-        d_inp = relu_bwd_sum(d_msg, msgs[0], 1.0, dzs)
-    elif d_inp is None:
+    if d_inp is None:
         d_inp = relu_bwd(d_msg, msgs[0], 1.0)
     else:
         relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
@@ -618,18 +652,20 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
     d_a, part = linear(nA, H, Wo.pk_t(ATOM_FDIM, ATOM_FDIM + H), w_packed=True, a1=dH, k1=H, a_mask=h, mask_scale=sign * ks,
                        dz_out=dz_o, colsum_w=g.npad)
     wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=g.f_atoms, k1=ATOM_FDIM, x2=a_last, k2=H, accumulate=acc0, side=True)
-    d_msg = gather_sum(d_a, g.b2t, H, row0_partial=part)
+    # per-copy W_h layers (it >= 1): gradients arrive masked from the gather that forms them (see mpn_backward); the one that
+    # reaches the shared prefix stays unmasked - gather_sum_masked masks it while summing over the copies
+    per_copy = depth - 2 >= 1
+    d_msg = gather_sum(d_a, g.b2t, H, row0_partial=part, mask=(msgs[depth - 1] if per_copy else None), mask_scale=ks)
     d_inp_full = None
     wh_started = acc0
     for it in reversed(range(1, depth - 1)):                         # per-copy W_h layers
-        dz = torch.empty_like(d_msg)
-        d_min, part = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
-                             dz_out=dz, colsum_w=g.npad_b)
+        dz = d_msg
+        d_min, part = linear(nB, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H, colsum_w=g.npad_b)
         wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
               accumulate=wh_started, side=True)
         wh_started = True
         d_inp_full = dz if d_inp_full is None else axpby(1.0, d_inp_full, 1.0, dz)   # fresh buffer (side-stream readers)
-        d_msg = bond_message_adjoint(d_min, g, H, part)
+        d_msg = bond_message_adjoint(d_min, g, H, part, mask=(msgs[it] if it - 1 >= 1 else None), mask_scale=ks)
     # ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
     dz1_u = gather_sum_masked(d_msg, msgs[1], ks, bmap_t, H)          # (msgs[1] > 0) <=> kept and z1 > 0; sum over the copies
     if d_inp_full is not None:
@@ -656,7 +692,7 @@ def mpndiff_forward(g, H: int, depth: int, Wi: LinW, Wh: Optional[LinW], Wo: Opt
     msg = _new(x, nA, H)
     first_p = p if depth == 0 else 0.0                                                   # :221 (depth 0: dropout(message))
     linear(nA, H, Wi.pk(Hin), w_packed=True, a1=x, k1=Hin, a1_sub=x_sub, a1_sub_idx=x_sub_idx, bias=Wi.b, act=ACT_RELU,
-           out=msg, c_pre=inp,
+           out=msg, c_pre=inp, want_bits=True,
            drop_p=first_p, seed=_site_seed(seed, 2000))                                  # :194-195
     msgs, amsgs = [msg], []
     a_last = None
@@ -689,56 +725,51 @@ def mpndiff_backward(g, H: int, depth: int, Wi: LinW, Wh, Wo, p: float, saved, x
     gWi, gbi = Wi.grads()
     gWh, gbh = (Wh.grads() if Wh is not None else (None, None))
     gWo, gbo = (Wo.grads() if Wo is not None else (None, None))
-    d_hid = segment_mean_bwd(dvecs, g, H, F, out_drop_p, out_seed)                        # [nA,H]
     d_x = None
-    if depth > 0:
-        fused = (H % 4 == 0)
-        # dX over both column segments of W_o: [d_x | d_a]; the first of the two GEMMs also writes the masked
-        # gradient dZ for the weight-gradient stream (see mpn_backward)
-        if fused:
-            dz_o = torch.empty_like(d_hid)
-            d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks, dz_out=dz_o)
-            wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx, x2=a_last, k2=H, side=True)
-        else:
-            wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx,
-                  x2=a_last, k2=H, side=True)
-            d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
-        if fused:
-            d_a, part = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks,
-                               colsum_w=g.npad)
-            d_msg = gather_sum(d_a, g.a2a_t, H, row0_partial=part)  # neighbour relation is symmetric
-        else:
-            d_a = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
-            d_msg = gather_sum(d_a, g.a2a_t, H)
-            _pad_row_fix(d_msg, d_a, g, H)
-        d_inp = None
+    fused = depth > 0 and H % 4 == 0
+    if fused:
+        # hid = drop(relu(.)): the readout's adjoint applies that pattern as it writes (dZ of W_o), so the dX GEMMs over both
+        # column segments of W_o ([d_x | d_a]) read a plain operand; the iterations below follow mpn_backward's fused form
+        dz_o = segment_mean_bwd(dvecs, g, H, F, out_drop_p, out_seed, mask=hid, mask_scale=ks)
+        d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=dz_o, k1=H)
+        wgrad(nA, H, dz_o, gWo, dbias=gbo, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx, x2=a_last, k2=H, side=True)
+        d_a, part = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=dz_o, k1=H, colsum_w=g.npad)
+        top = depth - 1
+        cur = gather_sum(d_a, g.a2a_t, H, row0_partial=part, mask=msgs[top], mask_scale=(1.0 if top == 0 else ks))  # neighbour relation is symmetric
         dzs = []
         fb = g.fb_sum() if depth > 1 else None
         for it in reversed(range(depth - 1)):
-            first = d_inp is None
-            if fused:
-                dz = torch.empty_like(d_msg)
-                d_a, part = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=d_msg, k1=H, a_mask=msgs[it + 1], mask_scale=ks,
-                                   dz_out=dz, colsum_w=g.npad)
-                wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2), side=True)
-                dzs.append(dz)
-                d_msg = gather_sum(d_a, g.a2a_t, H, row0_partial=part)   # fresh buffer (side-stream readers)
-                continue
-            else:
-                if first:                                            # see mpn_backward: fresh dz per iteration
-                    d_inp = torch.zeros_like(d_msg)
-                dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=torch.empty_like(d_msg), acc=d_inp)
-                wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2), side=True)
-                d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
+            dz = cur
+            d_a, part = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H, colsum_w=g.npad)
+            wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2), side=True)
+            dzs.append(dz)
+            cur = gather_sum(d_a, g.a2a_t, H, row0_partial=part, mask=msgs[it], mask_scale=(1.0 if it == 0 else ks),
+                             adds=(dzs if it == 0 else ()))
+        d_inp = cur
+    elif depth > 0:
+        d_hid = segment_mean_bwd(dvecs, g, H, F, out_drop_p, out_seed)                    # [nA,H]
+        wgrad(nA, H, d_hid, gWo, dbias=gbo, mask=hid, mask_scale=ks, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx,
+              x2=a_last, k2=H, side=True)
+        d_x = linear(nA, Hin, Wo.pk_t(0, Hin), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
+        d_a = linear(nA, H, Wo.pk_t(Hin, Hin + H), w_packed=True, a1=d_hid, k1=H, a_mask=hid, mask_scale=ks)
+        d_msg = gather_sum(d_a, g.a2a_t, H)
+        _pad_row_fix(d_msg, d_a, g, H)
+        d_inp = None
+        fb = g.fb_sum() if depth > 1 else None
+        for it in reversed(range(depth - 1)):
+            if d_inp is None:                                        # see mpn_backward: fresh dz per iteration
+                d_inp = torch.zeros_like(d_msg)
+            dz = relu_bwd(d_msg, msgs[it + 1], ks, dz=torch.empty_like(d_msg), acc=d_inp)
+            wgrad(nA, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x2=fb, k2=FBOND, accumulate=(it != depth - 2), side=True)
+            d_a = linear(nA, H, Wh.pk_t(0, H), w_packed=True, a1=dz, k1=H)
             d_msg = gather_sum(d_a, g.a2a_t, H)                     # fresh buffer (side-stream readers)
             _pad_row_fix(d_msg, d_a, g, H)
-        if fused:
-            d_inp = relu_bwd_sum(d_msg, msgs[0], 1.0, dzs)
-        elif d_inp is None:
+        if d_inp is None:
             d_inp = relu_bwd(d_msg, msgs[0], 1.0)
         else:
             relu_bwd(d_msg, msgs[0], 1.0, acc=d_inp, want_dz=False)
     else:
+        d_hid = segment_mean_bwd(dvecs, g, H, F, out_drop_p, out_seed)                    # [nA,H]
         d_inp = relu_bwd(d_hid, msgs[0], ks)                        # hid = drop(relu(inp))
     wgrad(nA, H, d_inp, gWi, dbias=gbi, x1=x, k1=Hin, x1_sub=x_sub, x1_sub_idx=x_sub_idx, side=True)
     if d_x is None:

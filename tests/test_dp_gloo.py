@@ -115,3 +115,38 @@ def test_bucket_single_process_is_a_scale():
     p.grad = torch.full((3,), 2.0)
     GradBucket([p]).allreduce(0.5)
     assert torch.equal(p.grad, torch.ones(3))
+
+
+def _mixed_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # an attached bucket with three kinds of parameter: one whose gradient was BORN in the bucket (the explicit
+        # backward's sink), one whose gradient autograd produced elsewhere (an extra head), one the step did not touch
+        a, b, c = (torch.nn.Parameter(torch.zeros(n)) for n in (5, 3, 4))
+        bucket = GradBucket([a, b, c]).attach()
+        try:
+            va = bucket.sink(a)
+            assert va is not None and va.data_ptr() == bucket.flat.data_ptr()
+            va.copy_(torch.arange(5.0) + rank)
+            a.grad = va
+            b.grad = torch.full((3,), 10.0 + rank)               # not a view of the flat buffer
+            bucket.allreduce(0.5)
+        finally:
+            bucket.detach()
+        ok = (torch.equal(a.grad, torch.arange(5.0) + 0.5) and torch.equal(b.grad, torch.full((3,), 10.5)) and
+              torch.equal(c.grad, torch.zeros(4)) and b.grad.data_ptr() == bucket._views[1].data_ptr())
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_attached_bucket_with_a_gradient_from_outside_the_explicit_backward():
+    """the pack fallback ran `cat(..., out=flat)` over gradients some of which already alias `flat`
+    (torch refuses overlapping input/output); the mixed case now copies only the outsiders into their views."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mixed_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

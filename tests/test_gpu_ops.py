@@ -362,3 +362,61 @@ def test_segment_mean_backward_is_the_adjoint_with_the_forward_dropout_stream(H,
     lhs = float((fwd[:, :H].double().cpu() * torch.as_tensor(dout[:, :H]).double()).sum())
     rhs = float((torch.as_tensor(x).double() * got.double().cpu()).sum())
     assert abs(lhs - rhs) <= 1e-5 * (1 + abs(lhs))                  # <fwd(x), dout> == <x, bwd(dout)>
+
+
+@pytest.mark.parametrize("H", [300, 600, 32])
+@pytest.mark.parametrize("K,n_adds,padrow", [(1, 0, True), (3, 2, True), (4, 5, True), (4, 1, False), (3, 7, True), (2, 15, False)])
+def test_gather_sum_epilogue_equals_the_separate_kernel_sequence(H, K, n_adds, padrow):
+    """rr_gather_sum_epi_f32 (ABI revision 4): out = mask(sum_k src[idx]) * scale + sum(adds) in ONE pass, bit-identical
+    to rr_gather_sum(_padrow)_f32 followed by rr_relu_bwd_sum_f32 - with the mask read as the f32 activation and as the
+    sign-bit image a split GEMM wrote for it (models/mpn.py:89-97 backward)."""
+    rng = np.random.default_rng(H + 10 * K + n_adds)
+    n_src, n_out = 1543, 977
+    src = dev(rng.standard_normal((n_src, H)).astype(np.float32))
+    idx = rng.integers(-1, n_src, size=(n_out, K)).astype(np.int32)
+    idx[5] = -1
+    adds = [dev(rng.standard_normal((n_out, H)).astype(np.float32)) for _ in range(n_adds)]
+    part = dev(rng.standard_normal((29, (H + 3) // 4 * 4)).astype(np.float32)) if padrow else None
+    # the mask: the output y of a split GEMM (ReLU + dropout), with its sign-bit image
+    W = torch.randn(H, H, device="cuda") / 17
+    x = torch.randn(n_out, H, device="cuda")
+    y = Fn.linear(n_out, H, Fn.LinW(W, None).pk(H), w_packed=True, a1=x, k1=H, act=Fn.ACT_RELU, drop_p=0.2, seed=9, want_bits=True)
+    assert getattr(y, "_rr_bits", None) is not None
+    y_plain = y.clone()                                              # same values, no sign-bit image attached
+    g = Fn.gather_sum(src, dev(idx), H, row0_partial=part)
+    want = Fn.relu_bwd_sum(g, y_plain, 1.25, adds)
+    got_bits = Fn.gather_sum(src, dev(idx), H, row0_partial=part, mask=y, mask_scale=1.25, adds=adds)
+    got_f32 = Fn.gather_sum(src, dev(idx), H, row0_partial=part, mask=y_plain, mask_scale=1.25, adds=adds)
+    assert torch.equal(got_bits, want) and torch.equal(got_f32, want)
+    # adds only / mask only
+    if n_adds:
+        assert torch.equal(Fn.gather_sum(src, dev(idx), H, row0_partial=part, adds=adds),
+                           Fn.relu_bwd_sum(g, torch.ones_like(g), 1.0, adds))
+    assert torch.equal(Fn.gather_sum(src, dev(idx), H, row0_partial=part, mask=y, mask_scale=1.25), Fn.relu_bwd(g, y_plain, 1.25))
+    ref = np.where(y.cpu().numpy() > 0, g.cpu().numpy() * np.float32(1.25), 0)
+    for t in adds:
+        ref = ref + t.cpu().numpy()
+    close(got_bits, ref, what="gather epilogue")
+
+
+def test_segment_mean_backward_with_the_fused_mask():
+    """rr_segment_mean_bwd_masked_f32 == rr_segment_mean_bwd_f32 followed by rr_relu_bwd_f32, f32 mask and sign bits."""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(11)
+    H, F, p = 300, 1, 0.1
+    sizes = rng.integers(1, 9, size=211)
+    M, nA = len(sizes), int(sizes.sum()) + 1
+    starts = np.concatenate([[1], 1 + np.cumsum(sizes)[:-1]])
+    a_scope = np.stack([starts, sizes], 1).astype(np.int32)
+    atom2mol = np.full(nA, -1, np.int32)
+    for m, (s0, n) in enumerate(a_scope):
+        atom2mol[s0:s0 + n] = m
+    g = SimpleNamespace(a_scope=dev(a_scope), atom2mol=dev(atom2mol), M=M, nA=nA)
+    dout = dev(rng.standard_normal((M, H + F)).astype(np.float32))
+    W = torch.randn(H, H, device="cuda") / 17
+    hid = Fn.linear(nA, H, Fn.LinW(W, None).pk(H), w_packed=True, a1=torch.randn(nA, H, device="cuda"), k1=H, act=Fn.ACT_RELU,
+                    drop_p=p, seed=3, want_bits=True)
+    plain = hid.clone()
+    want = Fn.relu_bwd(Fn.segment_mean_bwd(dout, g, H, F, p, 77), plain, 1.0 / (1.0 - p))
+    assert torch.equal(Fn.segment_mean_bwd(dout, g, H, F, p, 77, mask=hid, mask_scale=1.0 / (1.0 - p)), want)
+    assert torch.equal(Fn.segment_mean_bwd(dout, g, H, F, p, 77, mask=plain, mask_scale=1.0 / (1.0 - p)), want)

@@ -51,6 +51,8 @@ CASES = [
     (32, 3, 2, 3, True, 4, "with_softplus", None, 1, 0.0, False),       # evidential 4-parameter head
     (300, 3, 3, 3, True, 1, "with_softplus", None, 1, 0.1, True),       # the headline shape
     (600, 2, 2, 3, True, 2, "with_softplus", None, 1, 0.1, True),       # N = 600: two column blocks per row block
+    (32, 11, 12, 2, True, 1, "no_softplus", None, 1, 0.1, True),        # depth >= 10: more than 8 per-iteration dZ buffers
+    (32, 16, 16, 2, True, 1, "no_softplus", None, 0, 0.0, True),        # the deepest model a plan takes (MAXD)
 ]
 
 
