@@ -25,6 +25,30 @@ __device__ inline void st(float* p, typename Vec<VEC>::T v) {
 // out[r] = sum_k src[idx[r,k]]   (idx < 0 skipped)
 __device__ __attribute__((aligned(16))) const float gather_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
+// Element range of a block for the gather kernels.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one, each
+// with its own L2): with a plain grid-stride loop the K destinations that read one source row run on different XCDs and
+// every XCD pulls its own copy of the row.  Here block b works on the contiguous range number
+// (b % 8) * (G / 8) + b / 8, so one XCD covers one contiguous eighth of the rows - a molecule's rows sit next to each other,
+// its gathers stay inside one L2 (speed only; any mapping gives the same results).  G % 8 != 0: identity mapping.
+#ifndef RR_GATHER_NO_XCD_MAP
+__device__ inline void gather_block_range(int gblocks, int64_t total, int64_t* beg, int64_t* end) {
+  int vb = static_cast<int>(blockIdx.x);
+  if ((gblocks & 7) == 0) vb = (vb & 7) * (gblocks >> 3) + (vb >> 3);
+  int64_t per = (total + gblocks - 1) / gblocks;
+  per = (per + 255) & ~int64_t(255);                    // whole 256-thread passes: waves stay aligned to 1 KiB
+  *beg = static_cast<int64_t>(vb) * per;
+  const int64_t e = *beg + per;
+  *end = e < total ? e : total;
+}
+#define RR_GATHER_LOOP(e, gblocks, total)                                              \
+  int64_t e##_beg, e##_end;                                                             \
+  gather_block_range(gblocks, total, &e##_beg, &e##_end);                               \
+  for (int64_t e = e##_beg + threadIdx.x; e < e##_end; e += 256)
+#else
+#define RR_GATHER_LOOP(e, gblocks, total)                                              \
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += static_cast<int64_t>(gblocks) * blockDim.x)
+#endif
+
 // out[r] = sum_k (mask[j_k] > 0 ? src[j_k] * scale : 0): a ReLU / dropout backward (rr_relu_bwd_f32) folded into the gather
 // that consumes it - the same products in the same order, so the result equals the two-kernel sequence bit for bit, without
 // writing and re-reading the masked tensor.  Used where the masked tensor has no other reader: the shared-prefix reactant
@@ -36,7 +60,6 @@ __global__ void __launch_bounds__(256) gather_sum_masked_kernel(const float* __r
                                                                 int64_t ld_out) {
   using V = typename Vec<VEC>::T;
   const int64_t total = n_out * HV;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   auto masked = [&](V v, V m) -> V {
     if constexpr (VEC == 4) {
       V r;
@@ -47,7 +70,7 @@ __global__ void __launch_bounds__(256) gather_sum_masked_kernel(const float* __r
       return m > 0.f ? v * scale : 0.f;
     }
   };
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+  RR_GATHER_LOOP(e, static_cast<int>(gridDim.x), total) {
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * VEC;
     const int32_t* ir = idx + r * K;
@@ -105,8 +128,7 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
     }
     return;
   }
-  const int64_t stride = static_cast<int64_t>(gblocks) * blockDim.x;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+  RR_GATHER_LOOP(e, gblocks, total) {
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * VEC;
     if (r == 0 && row0_partial != nullptr) continue;          // written by the reduction blocks
@@ -209,8 +231,7 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
     }
     return;
   }
-  const int64_t stride = static_cast<int64_t>(gblocks) * blockDim.x;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+  RR_GATHER_LOOP(e, gblocks, total) {
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * 4;
     if (r == 0 && row0_partial != nullptr) continue;
@@ -287,8 +308,7 @@ __global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __rest
                                                              float* __restrict__ out, int64_t ld_out) {
   using V = typename Vec<VEC>::T;
   const int64_t total = n_out * HV;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+  RR_GATHER_LOOP(e, static_cast<int>(gridDim.x), total) {
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * VEC;
     const int32_t j = idx[r];

@@ -673,7 +673,15 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   constexpr int SRC_PANEL = NTP * 3 * 1024;            // ... and in the packed weights
   constexpr int S_BM = 16 * WAVES, S_THREADS = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const bias_s = reinterpret_cast<float*>(smem + 2 * PANEL);
+  // LDS layout.  k-loop: two weight images [0, 2 * PANEL).  Epilogue of the 12-wave geometry (RS_EPI): the images' space
+  // becomes twelve wave-private transposition regions of 8 rows x 77 float4 (the 77th is padding: rows 1232 bytes apart
+  // keep the eight lanes of a ds_write_b128 group on different banks), followed by the column-sum / sign-bit staging and
+  // the bias slice.  The 8-wave geometries keep bias and staging where they were.
+  constexpr bool RS_EPI = WAVES == 12;
+  constexpr int RS = 77, REGION = 8 * RS * 16;         // bytes per wave and pass
+  constexpr int CS_OFF = RS_EPI ? (WAVES * REGION > 2 * PANEL ? WAVES * REGION : 2 * PANEL) : 0;
+  constexpr int BIAS_OFF = RS_EPI ? CS_OFF + WAVES * BN * 4 : 2 * PANEL;
+  float* const bias_s = reinterpret_cast<float*>(smem + BIAS_OFF);
   const int t0 = blockIdx.y * NT;                      // first column tile of this workgroup
   const int nth = NTP - t0 < NT ? NTP - t0 : NT;       // its column tiles (the last workgroup of a row block may have fewer)
   const bool full = nth == NT;
@@ -682,6 +690,23 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   const rr_linear_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fkq = lane >> 4;
+  RR_STAMP(0);
+#ifdef RR_TRACE
+  if (rr_trace_buf && threadIdx.x == 0 && blockIdx.y == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    rr_trace_buf[static_cast<size_t>(blockIdx.x) * 8 + 4] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+  }
+#endif
+#ifdef RR_SPLIT_STAGGER
+  // experiment: de-phase the workgroups of the first round (equal work + simultaneous start = every CU in its store
+  // epilogue at the same time); later workgroups start when an earlier one retires and inherit the offsets
+  if (WAVES == 12 && gridDim.x > 256 && blockIdx.x < 256) {
+    const int ph = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < ph * RR_SPLIT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * S_BM;
   const int64_t m = m0 + wave * 16 + fr;
   const bool row_ok = m < a.M;
@@ -842,8 +867,19 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // weight image of step s+1, so "all but the youngest NX" = image landed, step s+1's chunks landed, step s+2's in flight.
   constexpr int NX = MODE == 0 ? 2 : (MODE == 3 ? 3 : 4);   // vector-memory instructions of one issue_x
   constexpr bool DEEP = WAVES == 12;                   // the 8-wave geometries (several workgroups per CU, <= 128 registers): one step ahead
+  // Waves of the second half ("late") split their operand at the START of the step that consumes it, the first half at
+  // the END of the step before: between two barriers every wave runs the same program, so without this all three waves of
+  // a SIMD finish their MFMA blocks together and then run their ~150 VALU instructions of fixup() together, matrix pipe
+  // idle (measured: 79 k shader cycles per 10 k-steps against 54.7 k of MFMA issue).  De-phased, one half's VALU runs
+  // beside the other half's MFMAs.  Same values in the same order: only WHEN a wave converts its operand changes.
+#ifdef RR_SPLIT_NO_LATE
+  const bool late = false;
+#else
+  const bool late = DEEP && uwave >= WAVES / 2;
+#endif
   auto step = [&](int s, int slot) {
     const bool more = s + 1 < nk, more2 = s + 2 < nk;
+    if (late) fixup(s, DEEP ? slot : 0);
     if (more) issue_w(s + 1);
     if (DEEP) {
       if (more2) issue_x(s + 2, slot);
@@ -858,7 +894,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     } else {
       rr_wait_vm0();
     }
-    if (more) fixup(s + 1, DEEP ? slot ^ 1 : 0);
+    if (more && !late) fixup(s + 1, DEEP ? slot ^ 1 : 0);
     __syncthreads();
   };
 
@@ -870,13 +906,15 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   issue_x(0, 0);
   if (DEEP && nk > 1) issue_x(1, 1);
   rr_wait_vm0();
-  fixup(0, 0);
+  if (!late) fixup(0, 0);
   __syncthreads();
+  RR_STAMP(1);
 
   for (int s = 0; s < nk; s += 2) {
     step(s, 0);
     if (s + 1 < nk) step(s + 1, 1);
   }
+  RR_STAMP(2);
 
   // ---- epilogue: the accumulator layout is that of linear_fast_kernel (a lane holds 4 consecutive columns of one row)
   const int nq = fkq * 4;
@@ -910,8 +948,131 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   uint32_t mb[5] = {0u, 0u, 0u, 0u, 0u};
   const bool cs_on = a.colsum_partial != nullptr;
   const float wrow = (cs_on && row_ok) ? a.colsum_w[mc] : 0.f;
-  float* const cs_lds = reinterpret_cast<float*>(smem);    // [waves][BN], the (now idle) weight image
-  {
+  float* const cs_lds = reinterpret_cast<float*>(smem + CS_OFF);    // [waves][BN] (8-wave geometries: the now idle weight image)
+  // ---- row-contiguous epilogue (12-wave geometry).  In the accumulator layout a 16-lane group holds 16 ROWS x 16 bytes:
+  // every global_load / global_store of the epilogue touches 64 different 128-byte lines for 1 KiB of payload, and the
+  // address coalescer - not HBM - sets its time (measured: 10.8 us per 192-row block for the plain store epilogue, 21 us
+  // with the residual read; a de-phased start of the workgroups changed nothing).  So the tile goes through LDS once: the
+  // accumulators are written in their own layout, read back lane-linear (a lane = 4 consecutive columns of a row, 64 lanes
+  // = 1 KiB of consecutive memory where ldc == N) and everything after the GEMM - bias, residual, ReLU, dropout, second
+  // output, sign bits, the store - happens in that layout with fully coalesced accesses.  Same operations in the same
+  // order per element, so the stored values are those of the accumulator-layout epilogue bit for bit.  The weighted
+  // column sums (dX GEMMs: no bias / residual / activation) are taken from the accumulators before the transposition;
+  // the rare combination of column sums WITH epilogue arithmetic keeps the accumulator-layout code below.
+  const bool plain_epi = !has_bias && a.residual == nullptr && !relu && P.drop_thr == 0u && prow == nullptr && !mb_on;
+  bool done = false;
+#ifndef RR_EPI_MODE
+#define RR_EPI_MODE 1
+#endif
+  // RR_EPI_MODE (A/B knob): 0 = accumulator-layout epilogue everywhere, 1 = row-contiguous only where the epilogue READS
+  // (a residual), 2 = row-contiguous everywhere it applies.  Measured (profiles/r03_experiments.txt): with a residual
+  // read 223 -> 196 us per 139k-row launch; store-only epilogues do not gain (their time is the store rate of the CU
+  // itself, not the address pattern) and pay the LDS round trip.
+  const bool want_rs = RR_EPI_MODE == 2 || (RR_EPI_MODE == 1 && a.residual != nullptr);
+  if (RS_EPI && want_rs && (!cs_on || plain_epi)) {
+    done = true;
+    if (cs_on) {
+#pragma unroll
+      for (int tc = 0; tc < NT; ++tc) {
+        f32x4 t = acc[tc] * wrow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = t[e];
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));   // row_shr:1
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));   // row_shr:2
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));   // row_shr:4
+          x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));   // row_shr:8
+          t[e] = x;
+        }
+        if (fr == 15) *reinterpret_cast<f32x4*>(cs_lds + wave * BN + tc * 16 + nq) = t;
+      }
+    }
+    unsigned char* const region = smem + uwave * REGION;
+    unsigned char* const bits_s = smem + CS_OFF + uwave * 640;       // [16 rows][40 bytes] (never together with column sums)
+    if (mb_on) {                                                     // the two pad bytes of a row stay zero
+#pragma unroll
+      for (int d = lane; d < 160; d += 64) reinterpret_cast<uint32_t*>(bits_s)[d] = 0u;
+    }
+    const int nqv = (a.N - n0) / 4 < 4 * NT ? (a.N - n0) / 4 : 4 * NT;   // valid float4 columns of this column block
+    const int64_t mw = m0 + uwave * 16;
+    const bool res_on = a.residual != nullptr;
+    constexpr int NI = (8 * 76 + 63) / 64;                           // lane-linear float4 reads per pass (76 per row, 8 rows)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if ((fr >> 3) == pass) {
+#pragma unroll
+        for (int tc = 0; tc < NT; ++tc)
+          *reinterpret_cast<f32x4*>(region + (((fr & 7) * RS + tc * 4 + fkq) << 4)) = acc[tc];
+      }
+      // (wave-private region: a wave's LDS operations execute in order, no barrier)
+      // lane-linear reads in groups of RG: the group's residual chunks are in flight together, then the group is finished
+      // (all NI at once would need 40 registers next to the 76 accumulators that stay live until pass 1 is written)
+      constexpr int RG = 2;
+#pragma unroll
+      for (int i0 = 0; i0 < NI; i0 += RG) {
+        asm volatile("" ::: "memory");
+        f32x4 rres[RG];
+#pragma unroll
+        for (int u = 0; u < RG; ++u) {
+          const int i = i0 + u;
+          if (i < NI && res_on) {
+            const int q = (64 * i) / 76, rem = (64 * i) % 76;
+            const bool wrap = rem + lane >= 76;
+            const int r = q + (wrap ? 1 : 0), c4 = rem + lane - (wrap ? 76 : 0);
+            const int64_t mm = mw + pass * 8 + r;
+            const bool ok = (64 * i + lane < 8 * 76) && c4 < nqv && mm < a.M;
+            const int64_t mmc = ok ? mm : 0;
+            const int64_t rr = a.residual_idx ? static_cast<int64_t>(ldgi(a.residual_idx + mmc)) : mmc;
+            rres[u] = ldg4((ok && rr >= 0) ? a.residual + rr * a.ldr + n0 + 4 * c4 : rr_zero_chunk);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RG; ++u) {
+          const int i = i0 + u;
+          if (i >= NI) continue;
+          const int q = (64 * i) / 76, rem = (64 * i) % 76;
+          const bool wrap = rem + lane >= 76;
+          const int r = q + (wrap ? 1 : 0), c4 = rem + lane - (wrap ? 76 : 0);
+          const int64_t mm = mw + pass * 8 + r;
+          const bool ok = (64 * i + lane < 8 * 76) && c4 < nqv && mm < a.M;
+          const int n = n0 + 4 * c4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(region + ((r * RS + c4) << 4));
+          if (has_bias) v = v + *reinterpret_cast<const f32x4*>(bias_s + 4 * (c4 < 4 * NT ? c4 : 0));
+          if (res_on) v = v + rres[u];
+          if (prow != nullptr && ok) *reinterpret_cast<f32x4*>(a.c_pre + mm * a.ld_pre + n) = v;
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (P.drop_thr != 0u) {
+            const uint64_t base = static_cast<uint64_t>(mm) * static_cast<uint64_t>(a.N) + static_cast<uint64_t>(n);
+            const uint32_t w = rr_hash_group(a.drop_seed, base >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rr_hash_lane(w, e) >= P.drop_thr ? v[e] * P.keep_scale : 0.f;
+          }
+          if (ok) *reinterpret_cast<f32x4*>(a.c + mm * a.ldc + n) = v;
+          if (mb_on) {                                               // lanes l, l^1 hold the two halves of 8 consecutive columns
+            uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            if (c4 >= nqv) nib = 0u;                                  // columns past N: zero bits
+            const uint32_t other = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 1) << 2, static_cast<int>(nib)));
+            const int j = c4 >> 1;                                   // columns 8j .. 8j+7: tile j/2, half j&1
+            if ((c4 & 1) == 0 && 64 * i + lane < 8 * 76 && c4 < 4 * NT)
+              bits_s[(pass * 8 + r) * 40 + (j & 1) * 20 + (j >> 1)] = static_cast<uint8_t>(nib | (other << 4));
+          }
+        }
+      }
+    }
+    if (mb_on) {                                                     // 16 rows x 10 dwords, coalesced
+      const int64_t rowb = mask_bits_row(a.N);
+#pragma unroll
+      for (int d = lane; d < 160; d += 64) {
+        const int r = d / 10, w = d - 10 * r;
+        if (mw + r < a.M)
+          *reinterpret_cast<uint32_t*>(a.mask_bits_out + (mw + r) * rowb + blockIdx.y * 40 + 4 * w) = reinterpret_cast<const uint32_t*>(bits_s)[d];
+      }
+    }
+  }
+  if (!done) {
     const bool res_ok = rrow != nullptr;
     const float* rbase = res_ok ? rrow : dummy;
     constexpr int D = 4;
@@ -963,7 +1124,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       }
     }
   }
-  if (NT == 19 && mb_on && row_ok && (fkq & 1) == 0) {
+  if (!done && NT == 19 && mb_on && row_ok && (fkq & 1) == 0) {
     uint32_t* d = reinterpret_cast<uint32_t*>(a.mask_bits_out + m * mask_bits_row(a.N) + blockIdx.y * 40 + (fkq >> 1) * 20);
 #pragma unroll
     for (int i = 0; i < 5; ++i) d[i] = mb[i];
@@ -982,6 +1143,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
         *reinterpret_cast<f32x4*>(a.colsum_partial + (static_cast<int64_t>(blockIdx.x) * (WAVES / 4) + h) * a.ld_partial + n) = s01 + s23;
     }
   }
+#ifdef RR_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RR_STAMP(3);
+#endif
 }
 
 // weight terms of the split path: dst = [k-step][column tile][term 0..2][lane 0..63][8 bf16], the LDS image of a k-step
@@ -1807,7 +1972,10 @@ inline bool vec_ok(const float* p, int64_t ld) { return p && rr_aligned16(p) && 
 
 template <int NTP, int NT, int MODE, int WAVES>
 int launch_split_one(const LinearParams& P, hipStream_t s) {
-  constexpr int smem = 2 * NT * 3 * 1024 + 16 * NT * 4;
+  // k-loop: two weight images + the bias slice; the 12-wave geometry's epilogue needs 12 transposition regions of
+  // 8 x 77 float4, the column-sum / sign-bit staging and the bias slice (linear_split_kernel, "LDS layout")
+  constexpr int panel2 = 2 * NT * 3 * 1024, bn4 = 16 * NT * 4;
+  constexpr int smem = WAVES == 12 ? ((12 * 8 * 77 * 16 > panel2 ? 12 * 8 * 77 * 16 : panel2) + 13 * bn4) : panel2 + bn4;
   // > 64 KiB of LDS has to be asked for once per kernel AND per device (the attribute lives with the device's code
   // object); atomics because two host threads may launch the same instantiation at once (setting it twice is harmless)
   static std::atomic<uint64_t> configured{0};          // bit d: done on device d (devices >= 64 set it every launch)

@@ -27,8 +27,9 @@ def standardize_pairwise(train_targets, val_targets, target_name: str = "ea"):
 def run_train(model: torch.nn.Module, scheduler, train_batches: Sequence, val_batches: Sequence,
               path_checkpoints: Union[str, List[str], None], optimizer, epochs: int, seed: int, gpu: int,
               train_strategy: str = "sum_session", task_type: str = "baseline", logger=None,
-              target_name: Optional[str] = "ea", save_metric: Optional[str] = None, sigma: float = 1.0):
-    """Returns the per-epoch history [{epoch, train_loss, top1, pred_top25_in_targ_top25, top1_in_pred_top25, checkpoint}]."""
+              target_name: Optional[str] = "ea", save_metric: Optional[str] = None, sigma: float = 1.0, epoch_hook=None):
+    """Returns the per-epoch history [{epoch, train_loss, top1, pred_top25_in_targ_top25, top1_in_pred_top25, checkpoint}].
+    epoch_hook(epoch, model, record): optional observer called after every epoch's validation (not in the reference)."""
     if train_strategy not in ("sum_session", "accelerate_grad") or task_type != "baseline":
         raise ValueError("reactranker_amd covers the RankNet strategies main_ranknet.py selects: train_strategy "
                          "'sum_session' / 'accelerate_grad' with task_type 'baseline'")
@@ -73,6 +74,8 @@ def run_train(model: torch.nn.Module, scheduler, train_batches: Sequence, val_ba
             raise Exception("Unknown save metric")
         history.append(dict(epoch=epoch + 1, train_loss=float(epoch_loss), top1=float(top1),
                             pred_top25_in_targ_top25=float(recall25), top1_in_pred_top25=float(top25), checkpoint=saved))
+        if epoch_hook is not None:
+            epoch_hook(epoch, model, history[-1])
         say("Epoch [{}/{}],train_loss,{:.4f}, average_score_top1,{:.4f}, average_pred_in_targ_top25%,{:.4f}"
             .format(epoch + 1, epochs, epoch_loss, top1, top25))
     return history

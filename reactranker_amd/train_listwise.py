@@ -100,11 +100,14 @@ def batch_loss(task_type: str, output, scope, targets, gpu, epoch: int = 0, epoc
 def train(model: torch.nn.Module, scheduler, train_batches: Union[Sequence, Callable[[int], Iterable]],
           val_batches: Sequence, path_checkpoints: Union[str, List[str], None], optimizer, epochs: int, seed: int, gpu: int,
           task_type: str = "mle", logger=None, save_metric: Optional[str] = None, max_coeff: float = 1e-4,
-          mean: float = 0.0, std: float = 1.0, target_name: Optional[str] = None, normalize_target=True):
+          mean: float = 0.0, std: float = 1.0, target_name: Optional[str] = None, normalize_target=True,
+          epoch_hook: Optional[Callable] = None):
     """Same control flow as the reference train(): fixed seed, per batch forward / loss / zero_grad / backward /
     optimizer.step / scheduler.step (train_listwise.py:287-290), validation with ranking_metrics after every epoch,
     checkpoint whenever the selected metric does not get worse (:310-350).  `train_batches` is a sequence, or a
-    callable epoch -> iterable (the reference reshuffles with seed=epoch, :178).  Returns the per-epoch history."""
+    callable epoch -> iterable (the reference reshuffles with seed=epoch, :178).  Returns the per-epoch history.
+    epoch_hook(epoch, model, record): optional observer called after every epoch's validation (not in the reference; the
+    trajectory tests read the validation scores through it)."""
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
     if target_name is not None:                       # raw targets: standardise / flip like the reference (:66-122)
@@ -169,6 +172,8 @@ def train(model: torch.nn.Module, scheduler, train_batches: Union[Sequence, Call
         rec = dict(epoch=epoch + 1, train_loss=float(loss.detach().sum()), top1=float(top1), top1_in_pred_top25=float(top25),
                    pred_top25_in_targ_top25=float(recall25), ndcg=[float(x) for x in ndcg], checkpoint=saved)
         history.append(rec)
+        if epoch_hook is not None:
+            epoch_hook(epoch, model, rec)
         say("Epoch [{}/{}], train_loss,{:.4f}, top1,{:.4f}, top1_in_pred_top25%,{:.4f}, pred_top25%_in_targ_top25%,{:.4f}"
             .format(epoch + 1, epochs, rec["train_loss"], top1, top25, recall25))
     return history
