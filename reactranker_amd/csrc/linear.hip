@@ -301,6 +301,8 @@ __device__ unsigned long long* rr_trace_buf = nullptr;
 #endif
 
 __device__ __attribute__((aligned(16))) const float rr_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+// a whole row of zeros (4 KiB): "no row" for loaders that walk a row with a wave-uniform column offset
+__device__ __attribute__((aligned(16))) const float rr_zero_row[1024] = {0.f};
 
 // ------------------------------------------------------------------------ fast path
 // Same math as linear_kernel, for the hot case: every A source 16-byte addressable and W in
@@ -666,7 +668,9 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 // columns of 192 rows - and <10, 10, 8> / <4, 4, 8> for narrow layers.  Cutting the 19 tiles into 10 + 9 (<19, 10, 8>:
 // 60 KB, <= 128 registers, TWO workgroups per CU whose store epilogues and MFMA loops overlap) was measured and lost:
 // both halves load and split the operand rows, 320 vs 236 us on the masked dX GEMM (profiles/r02_experiments.txt).
-template <int NTP, int NT, int MODE, int WAVES>
+// EPI: 0 = accumulator-layout epilogue, 1 = row-contiguous epilogue through LDS (12-wave geometry; chosen per launch,
+// see launch_split_one: separate instantiations keep each epilogue's registers out of the other's kernel)
+template <int NTP, int NT, int MODE, int WAVES, int EPI = 0>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_kernel(const LinearParams P) {
   constexpr int BN = 16 * NT;
   constexpr int PANEL = NT * 3 * 1024;                 // bytes of one k-step's weight image in LDS
@@ -758,7 +762,47 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   uint32_t rb[2] = {0u, 0u};                           // MODE 3: the 8 mask bits of a step's chunk pair
   u32x4 x0, x1, x2;                                    // the three bf16 terms of the current step's operand
 
+  // Interior k-steps (all 32 columns of the step inside the segment) of MODE 0 / 1 take a leaner path: the lane's row
+  // pointers are resolved ONCE (a missing row points at a row of zeros), a step adds its wave-uniform column offset, and
+  // fixup() needs no per-element selects.  ~27 of the ~90 vector instructions of a k-step; same loaded values, same
+  // arithmetic.  The last step of a segment (partial: K = 300 ends inside it) keeps the select form below.
+#ifndef RR_SPLIT_NO_FASTX
+  constexpr bool FASTX = (MODE == 0 || MODE == 1);
+#else
+  constexpr bool FASTX = false;
+#endif
+  const bool fastx_ok = FASTX && a.k1 <= 960 && a.k2 <= 960;
+  const float* const xb1 = (rowp1 != nullptr ? rowp1 : rr_zero_row) + fkq * 8;
+  const float* const xb2 = (rowp2 != nullptr ? rowp2 : rr_zero_row) + fkq * 8;
+  const float* const sb1 = (subp != nullptr ? subp : rr_zero_row) + fkq * 8;
+  auto interior = [&](int s) -> bool {                 // (wave-uniform)
+    if (!fastx_ok) return false;
+    return s < P.t1 ? (s + 1) * SK <= a.k1 : (s - P.t1 + 1) * SK <= a.k2;
+  };
   auto issue_x = [&](int s, int slot) {                // pure loads (unconditional, from a selected address)
+    if (FASTX && fastx_ok) {
+      const bool s1 = s < P.t1;
+      const int off = (s1 ? s : s - P.t1) * SK;          // wave-uniform
+      const float* p = (s1 ? xb1 : xb2) + off;
+      const float* q = (MODE == 1 && s1) ? sb1 + off : rr_zero_row;   // (segment 2 has no subtract source: zeros, the count of loads per step stays NX)
+      if (interior(s)) {
+        ra[slot][0] = ldg4(p);
+        ra[slot][1] = ldg4(p + 4);
+        if (MODE == 1) {
+          rs[slot][0] = ldg4(q);
+          rs[slot][1] = ldg4(q + 4);
+        }
+      } else {                                         // last step of a segment: chunks past its end read zeros
+        const int kl = off + fkq * 8, ks = s1 ? a.k1 : a.k2;
+        ra[slot][0] = ldg4(kl < ks ? p : rr_zero_row);
+        ra[slot][1] = ldg4(kl + 4 < ks ? p + 4 : rr_zero_row);
+        if (MODE == 1) {
+          rs[slot][0] = ldg4(kl < ks ? q : rr_zero_row);
+          rs[slot][1] = ldg4(kl + 4 < ks ? q + 4 : rr_zero_row);
+        }
+      }
+      return;
+    }
     const bool seg1 = s < P.t1;
     const int kl = (seg1 ? s : s - P.t1) * SK + fkq * 8;
     const float* p = seg1 ? rowp1 : rowp2;
@@ -786,7 +830,39 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       if (b < nth * 3) rr_glds16(src + b * 256, dst + b * 1024);
     }
   };
+  auto split8 = [&](const f32x4& v0, const f32x4& v1) {
+    uint32_t t0, t1, t2;
+    split_pair(v0.x, v0.y, t0, t1, t2); x0.x = t0; x1.x = t1; x2.x = t2;
+    split_pair(v0.z, v0.w, t0, t1, t2); x0.y = t0; x1.y = t1; x2.y = t2;
+    split_pair(v1.x, v1.y, t0, t1, t2); x0.z = t0; x1.z = t1; x2.z = t2;
+    split_pair(v1.z, v1.w, t0, t1, t2); x0.w = t0; x1.w = t1; x2.w = t2;
+  };
   auto fixup = [&](int s, int slot) {                  // first use of the loads: selects, mask / subtract, split
+    if (FASTX && fastx_ok) {
+      f32x4 v0 = ra[slot][0], v1 = ra[slot][1];
+      f32x4 u0 = f32x4(0.f), u1 = f32x4(0.f);
+      if (MODE == 1) { u0 = rs[slot][0]; u1 = rs[slot][1]; }
+      const bool s1 = s < P.t1;
+      const int ks = s1 ? a.k1 : a.k2;
+      if (!interior(s) && (ks & 3) != 0) {             // a 16-byte chunk that straddles the segment's end: per element
+        const int kl = (s1 ? s : s - P.t1) * SK + fkq * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = kl + e < ks ? v0[e] : 0.f;
+          v1[e] = kl + 4 + e < ks ? v1[e] : 0.f;
+          if (MODE == 1) {
+            u0[e] = kl + e < ks ? u0[e] : 0.f;
+            u1[e] = kl + 4 + e < ks ? u1[e] : 0.f;
+          }
+        }
+      }
+      if (MODE == 1) {
+        v0 = v0 - u0;
+        v1 = v1 - u1;
+      }
+      split8(v0, v1);
+      return;
+    }
     const bool seg1 = s < P.t1;
     const int kl = (seg1 ? s : s - P.t1) * SK + fkq * 8;
     const float* p = seg1 ? rowp1 : rowp2;
@@ -823,11 +899,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
         v1[e] = (oks && kl + 4 + e < ks && ((bits >> (4 + e)) & 1u)) ? v1[e] * a.mask_scale : 0.f;
       }
     }
-    uint32_t t0, t1, t2;
-    split_pair(v0.x, v0.y, t0, t1, t2); x0.x = t0; x1.x = t1; x2.x = t2;
-    split_pair(v0.z, v0.w, t0, t1, t2); x0.y = t0; x1.y = t1; x2.y = t2;
-    split_pair(v1.x, v1.y, t0, t1, t2); x0.z = t0; x1.z = t1; x2.z = t2;
-    split_pair(v1.z, v1.w, t0, t1, t2); x0.w = t0; x1.w = t1; x2.w = t2;
+    split8(v0, v1);
     if (MODE == 2 || MODE == 3) {                      // side output (k1 % 4 == 0: chunks are whole).  Stored HERE, after the
       if (dzrow != nullptr && seg1) {                  // step's load wait: the store then has the whole next MFMA block to retire
         if (kl < ks) *reinterpret_cast<f32x4*>(dzrow + kl) = v0;
@@ -961,15 +1033,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // the rare combination of column sums WITH epilogue arithmetic keeps the accumulator-layout code below.
   const bool plain_epi = !has_bias && a.residual == nullptr && !relu && P.drop_thr == 0u && prow == nullptr && !mb_on;
   bool done = false;
-#ifndef RR_EPI_MODE
-#define RR_EPI_MODE 1
-#endif
-  // RR_EPI_MODE (A/B knob): 0 = accumulator-layout epilogue everywhere, 1 = row-contiguous only where the epilogue READS
-  // (a residual), 2 = row-contiguous everywhere it applies.  Measured (profiles/r03_experiments.txt): with a residual
-  // read 223 -> 196 us per 139k-row launch; store-only epilogues do not gain (their time is the store rate of the CU
-  // itself, not the address pattern) and pay the LDS round trip.
-  const bool want_rs = RR_EPI_MODE == 2 || (RR_EPI_MODE == 1 && a.residual != nullptr);
-  if (RS_EPI && want_rs && (!cs_on || plain_epi)) {
+  if (RS_EPI && EPI == 1 && (!cs_on || plain_epi)) {
     done = true;
     if (cs_on) {
 #pragma unroll
@@ -1970,8 +2034,15 @@ int launch_linear(const LinearParams& P, hipStream_t s, bool fast) {
 
 inline bool vec_ok(const float* p, int64_t ld) { return p && rr_aligned16(p) && (ld % 4 == 0); }
 
-template <int NTP, int NT, int MODE, int WAVES>
-int launch_split_one(const LinearParams& P, hipStream_t s) {
+#ifndef RR_EPI_MODE
+#define RR_EPI_MODE 1
+#endif
+// RR_EPI_MODE (A/B knob): 0 = accumulator-layout epilogue everywhere, 1 = row-contiguous where the epilogue READS (a
+// residual), 2 = row-contiguous everywhere it applies.  Measured (profiles/r03_experiments.txt): with a residual read
+// 223 -> 196 us per isolated 139k-row launch; store-only epilogues do not gain and pay the LDS round trip; inside a
+// training step (kernels of three streams interleaved on the chip) the difference is within the noise.
+template <int NTP, int NT, int MODE, int WAVES, int EPI>
+int launch_split_epi(const LinearParams& P, hipStream_t s) {
   // k-loop: two weight images + the bias slice; the 12-wave geometry's epilogue needs 12 transposition regions of
   // 8 x 77 float4, the column-sum / sign-bit staging and the bias slice (linear_split_kernel, "LDS layout")
   constexpr int panel2 = 2 * NT * 3 * 1024, bn4 = 16 * NT * 4;
@@ -1982,14 +2053,22 @@ int launch_split_one(const LinearParams& P, hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return RR_ERR_LAUNCH;
   if (dev < 0 || dev >= 64 || !((configured.load(std::memory_order_acquire) >> dev) & 1u)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NTP, NT, MODE, WAVES>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NTP, NT, MODE, WAVES, EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return RR_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) configured.fetch_or(uint64_t(1) << dev, std::memory_order_release);
   }
   const dim3 grid(static_cast<unsigned>((P.a.M + 16 * WAVES - 1) / (16 * WAVES)), static_cast<unsigned>((NTP + NT - 1) / NT));
-  linear_split_kernel<NTP, NT, MODE, WAVES><<<grid, 64 * WAVES, smem, s>>>(P);
+  linear_split_kernel<NTP, NT, MODE, WAVES, EPI><<<grid, 64 * WAVES, smem, s>>>(P);
   return rr_launch_status();
+}
+template <int NTP, int NT, int MODE, int WAVES>
+int launch_split_one(const LinearParams& P, hipStream_t s) {
+  if (WAVES == 12 && (MODE == 0 || MODE == 1)) {       // (the dX forms, MODE 2 / 3, never carry a residual)
+    const bool rs = RR_EPI_MODE == 2 || (RR_EPI_MODE == 1 && P.a.residual != nullptr);
+    if (rs) return launch_split_epi<NTP, NT, MODE, WAVES, (WAVES == 12 && (MODE == 0 || MODE == 1)) ? 1 : 0>(P, s);
+  }
+  return launch_split_epi<NTP, NT, MODE, WAVES, 0>(P, s);
 }
 template <int NTP, int NT, int WAVES>
 int launch_split(const LinearParams& P, hipStream_t s) {
