@@ -587,6 +587,7 @@ def main():
             n = len(rd)
             log(f"streaming {n} distinct steps from {len(shard_paths)} shard file(s)")
             pf = SH.StepPrefetcher(rd, device, range(n), depth=3)
+            startup = pf.prime()                          # start-up latency of the pipeline, reported, not timed
             it = iter(pf)
             e_secs, e_per, _ = R.timed(lambda i: next(it), n)
             pf.close()
@@ -602,7 +603,7 @@ def main():
                          shard_files=len(shard_paths),
                          shard_gb_per_rank=round(sum(os.path.getsize(p) for p in shard_paths) / 1e9, 3),
                          step_mb=round(rd.max_step_bytes / 1e6, 2), h2d_gb_per_rank=round(pf.bytes_copied / 1e9, 3),
-                         consumer_wait_s=round(pf.wait_s, 4), pack_s=round(t_shards, 2),
+                         consumer_wait_s=round(pf.wait_s, 4), prefetch_startup_s=round(startup, 4), pack_s=round(t_shards, 2),
                          page_cache="hot",
                          note="every step read once from shard files written seconds earlier by this run, i.e. served from the "
                               "page cache, not from the disk (page cache -> pinned staging -> one H2D copy per step on a "

@@ -332,6 +332,14 @@ class StepPrefetcher:
         for f in futs:
             f.result()
 
+    def prime(self) -> float:
+        """Block until the first step's H2D copy has been issued (the pipeline's start-up latency: first page-cache
+        touches, first use of the pinned slots); returns the seconds waited.  Optional - iteration works without it."""
+        t0 = time.perf_counter()
+        while self.ready.empty() and self._err is None and self.thread.is_alive():
+            time.sleep(0.0005)
+        return time.perf_counter() - t0
+
     def _views(self, slot: int, i: int) -> Dict[str, torch.Tensor]:
         return _typed_views(self.dev[slot], ShardReader.toc(self.reader.blob(i)))
 
