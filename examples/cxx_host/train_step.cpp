@@ -4,8 +4,9 @@
 //
 // Reads one packed step from a shard file (layout: reactranker_amd/shards.py), uploads it with ONE copy, rebuilds the
 // feature arrays that do not travel (reactant rows = gathers of the distinct reactants' rows; f_bonds = f_atoms[b2a] ++
-// bond columns), then runs  rr_reaction_forward -> ListMLE (rr_listmle_fwd/bwd) -> rr_reaction_backward  and prints the
-// loss and one checksum per gradient tensor as JSON.  tests/test_gpu_cxx_host.py compares them with the Python modules
+// bond columns), then runs  rr_reaction_forward -> ListMLE (rr_listmle_fwd/bwd) -> rr_reaction_backward -> the gradient
+// all-reduce of a data-parallel job (rr_allreduce_f32; one rank here)  and prints the loss and one checksum per gradient
+// tensor as JSON.  tests/test_gpu_cxx_host.py compares them with the Python modules
 // on the same weights, step and dropout stream.
 //
 // Weights file: int32 header {H, depth, diff_depth, n_ffn, F, task_num, head}, then float32 tensors in the order
@@ -184,6 +185,22 @@ int main(int argc, char** argv) {
     gbuf.push_back({G.w[i], nw}); gbuf.push_back({G.b[i], static_cast<size_t>(Ls[i]->out)});
   }
   RR_OK_(rr_reaction_backward(&m, &s, dout, &G, 0, st));
+  // The data-parallel exchange of a multi-GPU job (one process per GPU, whole queries per rank): ONE sum all-reduce per
+  // gradient buffer over an RCCL communicator, scaled to the mean over equal shards.  This example is one process, so its
+  // communicator has one rank and the exchange is the identity - the call sequence is what a rank of an N-GPU job runs
+  // (rank 0 makes the id, every rank gets it over any host channel).  RR_CXX_DP=0 skips it (no RCCL on the machine).
+  const char* dp_env = getenv("RR_CXX_DP");
+  if (dp_env == nullptr || atoi(dp_env) != 0) {
+    char id[RR_COMM_ID_BYTES];
+    rr_comm_t comm = nullptr;
+    const int n_ranks = 1, rank = 0;
+    RR_OK_(rr_comm_unique_id(id));
+    RR_OK_(rr_comm_init_rank(&comm, n_ranks, id, rank));
+    for (auto& gb : gbuf)
+      if (gb.first) RR_OK_(rr_allreduce_f32(gb.first, static_cast<int64_t>(gb.second), 1.0f / n_ranks, comm, st));
+    HIP_OK(hipStreamSynchronize(st));
+    RR_OK_(rr_comm_destroy(comm));
+  }
   HIP_OK(hipStreamSynchronize(st));
 
   float loss = 0.f;

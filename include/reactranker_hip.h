@@ -438,8 +438,8 @@ int rr_derive_tables(const int32_t* a2b, const int32_t* b2a, const int32_t* b2re
  * caller-provided workspace whose layout is a pure function of (model, step): rr_reaction_backward re-derives every
  * saved address, the library keeps no state between the two calls.  Requirements: H % 4 == 0, 16-byte aligned rows
  * (what the packer produces); other shapes use the per-op entry points.  Device pointers unless noted.
- * The gradient all-reduce of a data-parallel job is deliberately NOT part of this ABI: the communicator belongs to the
- * launcher (torch.distributed / RCCL); a step is forward, loss kernel, backward, then the host's collective. */
+ * A data-parallel step is forward, loss kernel, backward, then ONE all-reduce of the gradient buffers handed to
+ * rr_reaction_backward (rr_allreduce_f32 below, or the host's own collective - the Python mirror uses torch.distributed). */
 #define RR_MAX_FFN 8
 
 typedef struct rr_graph {             /* a packed batch resident in HBM (arrays of rr_pack_graphs / rr_derive_*) */
@@ -498,6 +498,24 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step);
 int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, rr_stream_t stream);
 int rr_reaction_backward(const rr_model* model, const rr_step* step, const float* dout, const rr_grads* grads, int flags,
                          rr_stream_t stream);
+
+/* ------------------------------------------------------------------ data-parallel gradient exchange (RCCL) --- */
+/* Queries are independent: one process per GPU, whole queries per rank, identical replicas, and ONE sum all-reduce of the
+ * gradient buffers per optimizer step (the reference itself is single-process).  `comm` is an RCCL
+ * communicator (ncclComm_t): either one the host created with the RCCL it links - pass it as is - or one made by
+ * rr_comm_init_rank below.  RCCL is resolved at run time (symbols already in the process first, then librccl.so.1), so this
+ * library has no link-time dependency on it; RR_ERR_UNSUPPORTED when no RCCL can be found.
+ *   rr_allreduce_f32: buf[0:n] <- scale * sum over ranks of buf[0:n], in place, enqueued on `stream` (the all-reduce, then
+ *   one scaling pass unless scale == 1).  With equal shards pass scale = 1 / n_ranks; with ragged shards scale the local
+ *   gradient by local_count / global_count first (reactranker_amd.dp.loss_weight names the count per loss) and pass 1.
+ *   rr_comm_unique_id: rank 0 fills `id` (RR_COMM_ID_BYTES host bytes) and hands it to the other ranks by any host channel;
+ *   rr_comm_init_rank: collective over all ranks, each on its own current device. */
+typedef void* rr_comm_t;
+#define RR_COMM_ID_BYTES 128
+int rr_comm_unique_id(void* id);
+int rr_comm_init_rank(rr_comm_t* comm, int n_ranks, const void* id, int rank);
+int rr_comm_destroy(rr_comm_t comm);
+int rr_allreduce_f32(float* buf, int64_t n, float scale, rr_comm_t comm, rr_stream_t stream);
 
 /* Bond-to-bond backward table (HOST pointers), derived from the tables above.  The adjoint of
  *   message[b] = a_message[b2a[b]] - message[b2revb[b]],  a_message[a] = sum_k message[a2b[a,k]]   (models/mpn.py:89-92)

@@ -183,6 +183,10 @@ _SIGS = {
     "rr_reaction_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(Step)]),
     "rr_reaction_forward": (i32, [C.POINTER(Model), C.POINTER(Step), i32, c_stream]),
     "rr_reaction_backward": (i32, [C.POINTER(Model), C.POINTER(Step), c_f32p, C.POINTER(Grads), i32, c_stream]),
+    "rr_comm_unique_id": (i32, [C.c_void_p]),
+    "rr_comm_init_rank": (i32, [C.POINTER(C.c_void_p), i32, C.c_void_p, i32]),
+    "rr_comm_destroy": (i32, [C.c_void_p]),
+    "rr_allreduce_f32": (i32, [c_f32p, i64, f32, C.c_void_p, c_stream]),
     "rr_derive_bond_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, i32,
                                     C.c_void_p, C.c_void_p]),
     "rr_derive_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, C.c_void_p, i64, C.c_void_p,

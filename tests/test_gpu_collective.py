@@ -1,0 +1,40 @@
+"""rr_allreduce_f32: the gradient exchange of a data-parallel job behind the C-ABI.  One GPU per
+box here, so the communicator has ONE rank: what is checked is the binding (RCCL resolved at run time, communicator made
+through rr_comm_unique_id / rr_comm_init_rank, the collective enqueued on the caller's stream, the scaling pass, status
+codes) - the N-rank arithmetic is RCCL's own; the weighting that makes the reduced gradient equal the single-process one
+is proven with 2 gloo processes in tests/test_dp_gloo.py."""
+import ctypes as C
+
+import pytest
+import torch
+
+from reactranker_amd._lib import check, lib, ptr, stream
+
+
+def test_allreduce_argument_checks_need_no_gpu():
+    l = lib()
+    assert l.rr_allreduce_f32(None, 0, 1.0, None, None) == -1            # RR_ERR_ARG: null buffer / communicator
+    assert l.rr_comm_destroy(None) == -1
+    assert l.rr_comm_init_rank(None, 1, None, 0) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,scale", [(790_101, 0.5), (64, 1.0), (3, 0.25)])
+def test_allreduce_over_a_one_rank_communicator(n, scale):
+    l = lib()
+    ident = (C.c_char * 128)()
+    check(l.rr_comm_unique_id(ident), "rr_comm_unique_id")
+    comm = C.c_void_p()
+    check(l.rr_comm_init_rank(C.byref(comm), 1, ident, 0), "rr_comm_init_rank")
+    try:
+        x = torch.randn(n + 1, device="cuda")[1:]                           # (an unaligned start exercises the scalar tail)
+        y = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                        # enqueued on the caller's stream, not the null stream
+            check(l.rr_allreduce_f32(ptr(y), n, scale, comm, stream()), "rr_allreduce_f32")
+        side.synchronize()
+        assert torch.equal(y, x * scale)
+        check(l.rr_allreduce_f32(ptr(y), 0, 1.0, comm, stream()), "empty buffer")
+    finally:
+        check(l.rr_comm_destroy(comm), "rr_comm_destroy")
