@@ -217,7 +217,7 @@ def load_traffic():
         d = json.load(open(tf[-1]))
         if d.get("csrc_hash") != csrc_hash():
             return {}, f"{os.path.basename(tf[-1])} is stale (kernel sources changed since it was collected)"
-        return {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items()}, os.path.basename(tf[-1])
+        return {k: (v["hbm_bytes_per_launch"], v.get("launches", 1)) for k, v in d["kernels"].items()}, os.path.basename(tf[-1])
     except Exception as e:                                # noqa: BLE001
         return {}, f"unreadable ({e})"
 
@@ -240,7 +240,17 @@ def summarise(recs, traffic):
         return roof, roof_g, ktable
 
     def tr(key):
-        return traffic.get(key.replace("gather_sum_kernel", "gather_sum_kernel<4>"), traffic.get(key))
+        """PMC bytes per launch of a live-timing key.  rocprofv3 names every template instantiation; a key covers the
+        instantiations that differ only in trailing parameters the events do not tell apart (the epilogue variant of the
+        split GEMM, the addend count of the epilogue gather): launch-weighted mean over them."""
+        if key in traffic:
+            return traffic[key][0]
+        stem = key[:-1] + "," if key.endswith(">") else key + "<"
+        hits = [v for k, v in traffic.items() if k.startswith(stem)]
+        if key == "gather_sum_kernel":
+            hits = [traffic[k] for k in ("gather_sum_kernel<4>",) if k in traffic]
+        n = sum(h[1] for h in hits)
+        return round(sum(h[0] * h[1] for h in hits) / n) if n else None
     agg = {}
     for key, flops, nbytes, e0, e1 in recs:
         a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
