@@ -8,8 +8,8 @@
 kernels need.  `DeviceGraph` is its resident-in-HBM form; it is uploaded once per batch
 object and cached (the reference re-copies five tensors per forward, models/mpn.py:77).
 
-SMILES featurisation itself (RDKit) is out of scope: molecules
-enter as `synth.MolSpec` arrays or as any object with the reference MolGraph's attributes.
+Molecules enter as `synth.MolSpec` arrays, as any object with the reference MolGraph's attributes, or - when RDKit
+is installed - as SMILES through the optional featuriser in rdkit_features.py.
 """
 from __future__ import annotations
 
@@ -37,14 +37,20 @@ def get_bond_fdim() -> int:
 class MolGraph:
     """Single-molecule graph (reference featurization.py:135-210) backed by arrays.
 
-    Build with `MolGraph.from_spec(spec)`; constructing from a SMILES string needs RDKit,
-    which this environment does not have.
+    `MolGraph(smiles)` featurises through RDKit when the package is installed (rdkit_features.py: the reference's
+    feature layout, atom order and bond numbering) and raises a RuntimeError that says so when it is not;
+    `MolGraph.from_spec(spec)` wraps arrays that already exist.
     """
 
     def __init__(self, smiles: str = None, reaction: bool = True, atom_messages: bool = False, *, spec: MolSpec = None):
         if spec is None:
-            raise RuntimeError("MolGraph(smiles) needs RDKit featurisation, which is outside the HIP hot path; "
-                               "use MolGraph.from_spec(MolSpec) or pass reference MolGraph objects")
+            if smiles is None:
+                raise ValueError("MolGraph needs a SMILES / InChI string or spec=MolSpec")
+            if atom_messages:
+                raise ValueError("atom_messages=True drops the atom features from f_bonds; the encoder (bond_fdim 83) "
+                                 "never uses that form")
+            from . import rdkit_features
+            spec = rdkit_features.spec_from_smiles(smiles, reaction)
         self.spec = spec
         self.smiles = spec.smiles if smiles is None else smiles
         self.n_atoms = spec.n_atoms
@@ -499,9 +505,9 @@ def device_graph_of(batch, gpu) -> DeviceGraph:
     return dg
 
 
-def mol2graph(smiles_batch):
-    """Reference featurization.py:338-350 — needs RDKit."""
-    return BatchMolGraph([MolGraph(s) for s in smiles_batch])
+def mol2graph(smiles_batch, reaction: bool = True):
+    """Reference featurization.py:338-350: SMILES list -> BatchMolGraph (needs RDKit, see MolGraph)."""
+    return BatchMolGraph([MolGraph(s, reaction=reaction) for s in smiles_batch])
 
 
 # ---- packed on-disk format (SURVEY.md section 8f-2): the packer's host arrays as one .npz per batch ------------

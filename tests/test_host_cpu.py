@@ -291,3 +291,54 @@ def test_packer_under_address_sanitizer():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "no report" in r.stdout
+
+
+def test_smiles_featuriser_layout_matches_the_reference_molgraph(golden_dir):
+    """reactranker_amd.rdkit_features against what the REFERENCE's MolGraph (featurization.py:135-210) produced for the
+    same molecule descriptions, both served through tests/fake_rdkit.py (tools/make_golden.py gen_featurizer): every
+    one-hot block with its unknown slot, atom order by (repeated / zero) map number, bond numbering, f_bonds = atom ||
+    bond features, and the same arrays after the native packer."""
+    import json
+    from tests import fake_rdkit
+    from reactranker_amd import rdkit_features as RF
+    g = np.load(os.path.join(golden_dir, "featurizer.npz"))
+    descs = json.loads(str(g["descriptions"]))
+    assert descs == json.loads(json.dumps(fake_rdkit.descriptions())), "fixture and tests/fake_rdkit.py disagree: regenerate"
+    chem = fake_rdkit.chem_namespace(descs)
+    specs = []
+    for name in descs:
+        for reaction, tag in ((True, "rxn"), (False, "plain")):
+            spec = RF.spec_from_smiles(name, reaction, chem=chem)
+            k = f"{name}.{tag}"
+            assert spec.n_atoms == g[k + ".f_atoms"].shape[0] and spec.n_bonds == g[k + ".b2a"].shape[0]
+            np.testing.assert_array_equal(spec.f_atoms, g[k + ".f_atoms"])
+            f_bonds, b2a, b2revb, a2b = spec.directed()
+            np.testing.assert_array_equal(f_bonds, g[k + ".f_bonds"])
+            np.testing.assert_array_equal(b2a, g[k + ".b2a"])
+            np.testing.assert_array_equal(b2revb, g[k + ".b2revb"])
+            for i, row in enumerate(a2b):
+                want = g[k + ".a2b"][i]
+                assert row == [int(v) for v in want[want >= 0]]
+            if reaction:
+                specs.append(spec)
+    # ... and through MolGraph / the native packer: the batch's feature rows are the molecules' rows in order
+    mg = [featurization.MolGraph.from_spec(s) for s in specs]
+    bg = featurization.BatchMolGraph(mg)
+    fa = bg.f_atoms.numpy()
+    off = 1
+    for s in specs:
+        np.testing.assert_array_equal(fa[off:off + s.n_atoms], s.f_atoms)
+        off += s.n_atoms
+    assert off == bg.n_atoms
+    with pytest.raises(ValueError):
+        RF.spec_from_smiles("not in the table", True, chem=chem)
+
+
+def test_molgraph_from_smiles_says_what_is_missing_without_rdkit():
+    from reactranker_amd import rdkit_features as RF
+    if RF.available():
+        pytest.skip("RDKit is installed here")
+    with pytest.raises(RuntimeError, match="RDKit"):
+        featurization.MolGraph("CCO")
+    with pytest.raises(RuntimeError, match="RDKit"):
+        featurization.mol2graph(["CCO", "CC"])

@@ -13,6 +13,7 @@ BatchMolGraph as duck-typed MolGraph objects, weights come from a numpy formula
   ranknet: the real factorized_training_loop ('sum_session' and 'accelerate_grad') driven
            with stub data-processor / optimizer objects
   metrics: reactranker.metrics.NDCG / DCG, train.eval.compute_NDCG, eval's sorted() ordering
+  featurizer: MolGraph(smiles) on molecule descriptions served through a stand-in Chem namespace (tests/fake_rdkit.py)
 
 Usage: python tools/make_golden.py            (writes tests/golden/)
 """
@@ -563,6 +564,36 @@ def gen_standardize():
     print("wrote standardize.npz:", i, "listwise variants, 2 pairwise;", out["l0.train"][:3], out["l2.train"][:3])
 
 
+def gen_featurizer():
+    """The reference's own MolGraph (featurization.py:135-210) on molecule descriptions served through a stand-in Chem
+    namespace (tests/fake_rdkit.py): pins feature layout, atom order and bond numbering - not RDKit's chemistry."""
+    from reactranker.features import featurization as ref_feat
+    from tests import fake_rdkit
+    descs = fake_rdkit.descriptions()
+    fake = fake_rdkit.chem_namespace(descs)
+    # the enumerations the reference froze at import (this script's stub) and the stand-in's must agree
+    assert [fake.rdchem.HybridizationType.SP, fake.rdchem.HybridizationType.SP3D2] == [ref_feat.Chem.rdchem.HybridizationType.SP, ref_feat.Chem.rdchem.HybridizationType.SP3D2]
+    assert [fake.BondType.SINGLE, fake.BondType.AROMATIC] == [ref_feat.Chem.BondType.SINGLE, ref_feat.Chem.BondType.AROMATIC]
+    ref_feat.Chem.MolFromSmiles = fake.MolFromSmiles
+    ref_feat.Chem.AddHs = fake.AddHs
+    ref_feat.Chem.RemoveHs = fake.RemoveHs
+    out = {"descriptions": np.array(json.dumps(descs))}
+    for name in descs:
+        for reaction in (True, False):
+            g = ref_feat.MolGraph(name, reaction=reaction)
+            k = f"{name}.{'rxn' if reaction else 'plain'}"
+            out[k + ".f_atoms"] = np.asarray(g.f_atoms, np.float32).reshape(g.n_atoms, ATOM_FDIM)
+            out[k + ".f_bonds"] = np.asarray(g.f_bonds, np.float32).reshape(g.n_bonds, ATOM_FDIM + BOND_FDIM)
+            out[k + ".b2a"] = np.asarray(g.b2a, np.int32)
+            out[k + ".b2revb"] = np.asarray(g.b2revb, np.int32)
+            a2b = np.full((g.n_atoms, max([len(r) for r in g.a2b] + [1])), -1, np.int32)
+            for i, r in enumerate(g.a2b):
+                a2b[i, :len(r)] = r
+            out[k + ".a2b"] = a2b
+    np.savez_compressed(os.path.join(OUT, "featurizer.npz"), **out)
+    print("wrote featurizer.npz:", len(descs), "molecule descriptions x 2 atom orders")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -580,3 +611,4 @@ if __name__ == "__main__":
     gen_eval_metrics()
     gen_train_utils()
     gen_standardize()
+    gen_featurizer()
