@@ -49,6 +49,57 @@ __device__ inline void gather_block_range(int gblocks, int64_t total, int64_t* b
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += static_cast<int64_t>(gblocks) * blockDim.x)
 #endif
 
+// The element walk of the gather-sum kernels for pad widths 1..4 (16-byte chunks).  A destination chunk costs two dependent
+// memory round trips - its index row (L2), then the source rows (HBM) - and a thread walks ~5 chunks of its block's range.
+// Here (i) all KT row loads of a chunk are in flight together whatever KT is (the generic loop below serialises the
+// K % 4 remainder: with the bond-to-bond table's K = 3 that was three dependent round-trip pairs per chunk), (ii) the
+// index row of the thread's NEXT chunk is fetched before the current chunk's rows are waited for, and (iii) (row, column)
+// advance by increments instead of a 64-bit division per chunk.  Sums are formed in table order, ((0 + v0) + v1) + ...,
+// exactly as before.  pre(r, c) issues whatever else the epilogue reads (its loads fly with the rows); finish(r, c, acc, aux)
+// applies it and stores.
+#if !defined(RR_GATHER_NO_XCD_MAP) && !defined(RR_GATHER_NO_WALK)
+#define RR_GATHER_WALK 1
+template <int KT, typename PRE, typename FIN>
+__device__ __forceinline__ void gather_walk(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
+                                            int K, int HV, int64_t beg, int64_t end, PRE&& pre, FIN&& finish) {
+  int64_t e = beg + threadIdx.x;
+  if (e >= end) return;
+  const int quo = 256 / HV, rem = 256 - quo * HV;
+  int64_t r = e / HV;
+  int q = static_cast<int>(e - r * HV);
+  int32_t j[KT], jn[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) j[k] = idx[r * K + k];
+  while (true) {
+    int64_t rn = r + quo;
+    int qn = q + rem;
+    if (qn >= HV) {
+      qn -= HV;
+      ++rn;
+    }
+    const bool more = e + 256 < end;
+    const int32_t* irn = idx + (more ? rn : r) * K;     // (unconditional loads from a valid row)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) jn[k] = irn[k];
+    const int c = q * 4;
+    f32x4 v[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) v[k] = ld<4>(j[k] >= 0 ? src + j[k] * ld_src + c : gather_zero);
+    auto aux = pre(r, c);
+    f32x4 acc = f32x4(0.0f);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc = acc + v[k];
+    finish(r, c, acc, aux);
+    if (!more) break;
+    e += 256;
+    r = rn;
+    q = qn;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) j[k] = jn[k];
+  }
+}
+#endif
+
 // out[r] = sum_k (mask[j_k] > 0 ? src[j_k] * scale : 0): a ReLU / dropout backward (rr_relu_bwd_f32) folded into the gather
 // that consumes it - the same products in the same order, so the result equals the two-kernel sequence bit for bit, without
 // writing and re-reading the masked tensor.  Used where the masked tensor has no other reader: the shared-prefix reactant
@@ -128,6 +179,24 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
     }
     return;
   }
+#ifdef RR_GATHER_WALK
+  if constexpr (VEC == 4) {
+    if (K >= 1 && K <= 4) {
+      int64_t wbeg, wend;
+      gather_block_range(gblocks, total, &wbeg, &wend);
+      const bool skip0 = row0_partial != nullptr;
+      auto pre = [](int64_t, int) { return 0; };
+      auto fin = [&](int64_t r, int c, f32x4 acc, int) {
+        if (!(skip0 && r == 0)) st<4>(out + r * ld_out + c, acc);   // (row 0: written by the reduction blocks)
+      };
+      if (K == 4) gather_walk<4>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      else if (K == 3) gather_walk<3>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      else if (K == 2) gather_walk<2>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      else gather_walk<1>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      return;
+    }
+  }
+#endif
   RR_GATHER_LOOP(e, gblocks, total) {
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * VEC;
@@ -176,6 +245,42 @@ __device__ inline uint32_t epi_nibble(const uint8_t* bits, int64_t bits_row, int
   const int blk = c / 304, cc = c - blk * 304;
   const uint32_t b = bits[r * bits_row + blk * 40 + ((cc & 15) >> 3) * 20 + (cc >> 4)];
   return (b >> (cc & 4)) & 0xFu;
+}
+
+// what the epilogue reads for one chunk, issued before the gathered rows are waited for (gather_walk's pre())
+template <int NADD>
+struct EpiAux {
+  uint32_t nib;
+  f32x4 m;
+  f32x4 a[NADD > 0 ? NADD : 1];
+};
+template <int NADD>
+__device__ __forceinline__ EpiAux<NADD> epi_load(const GatherEpi& E, int64_t r, int c) {
+  static_assert(NADD >= 0, "run-time addend counts take epi_apply");
+  EpiAux<NADD> x;
+  x.nib = 0u;
+  x.m = f32x4(0.f);
+  if (E.bits != nullptr) x.nib = epi_nibble(E.bits, E.bits_row, r, c);
+  else if (E.mask != nullptr) x.m = ld<4>(E.mask + r * E.ld_mask + c);
+#pragma unroll
+  for (int j = 0; j < NADD; ++j) x.a[j] = ld<4>(E.adds[j] + r * E.ld_add + c);
+  return x;
+}
+template <int NADD>
+__device__ __forceinline__ f32x4 epi_finish(const GatherEpi& E, f32x4 g, const EpiAux<NADD>& x) {   // = epi_apply on loaded values
+  f32x4 v = g;
+  if (E.bits != nullptr) {
+    v.x = (x.nib & 1u) ? g.x * E.scale : 0.f; v.y = (x.nib & 2u) ? g.y * E.scale : 0.f;
+    v.z = (x.nib & 4u) ? g.z * E.scale : 0.f; v.w = (x.nib & 8u) ? g.w * E.scale : 0.f;
+  } else if (E.mask != nullptr) {
+    v.x = x.m.x > 0.f ? g.x * E.scale : 0.f; v.y = x.m.y > 0.f ? g.y * E.scale : 0.f;
+    v.z = x.m.z > 0.f ? g.z * E.scale : 0.f; v.w = x.m.w > 0.f ? g.w * E.scale : 0.f;
+  }
+  if (NADD == 0) return v;
+  f32x4 s = f32x4(0.f);
+#pragma unroll
+  for (int j = 0; j < NADD; ++j) s = s + x.a[j];
+  return s + v;
 }
 
 // NADD >= 0: that many addends, unrolled (their loads fly with the gather's); NADD < 0: E.n_adds at run time
@@ -231,6 +336,24 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
     }
     return;
   }
+#ifdef RR_GATHER_WALK
+  if constexpr (NADD >= 0) {
+    if (K >= 1 && K <= 4) {
+      int64_t wbeg, wend;
+      gather_block_range(gblocks, total, &wbeg, &wend);
+      const bool skip0 = row0_partial != nullptr;
+      auto pre = [&](int64_t r, int c) { return epi_load<NADD>(E, r, c); };
+      auto fin = [&](int64_t r, int c, f32x4 acc, const EpiAux<NADD>& x) {
+        if (!(skip0 && r == 0)) st<4>(out + r * ld_out + c, epi_finish<NADD>(E, acc, x));
+      };
+      if (K == 4) gather_walk<4>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      else if (K == 3) gather_walk<3>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      else if (K == 2) gather_walk<2>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      else gather_walk<1>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      return;
+    }
+  }
+#endif
   RR_GATHER_LOOP(e, gblocks, total) {
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * 4;
