@@ -56,10 +56,11 @@ __device__ inline void gather_block_range(int gblocks, int64_t total, int64_t* b
 // index row of the thread's NEXT chunk is fetched before the current chunk's rows are waited for, and (iii) (row, column)
 // advance by increments instead of a 64-bit division per chunk.  Sums are formed in table order, ((0 + v0) + v1) + ...,
 // exactly as before.  pre(r, c) issues whatever else the epilogue reads (its loads fly with the rows); finish(r, c, acc, aux)
-// applies it and stores.
+// applies it and stores.  Two chunks per thread in flight (e and e + 256 together) were measured and are no faster: with the
+// index prefetch the walk is no longer latency-bound (profiles/r03_experiments.txt).
 #if !defined(RR_GATHER_NO_XCD_MAP) && !defined(RR_GATHER_NO_WALK)
 #define RR_GATHER_WALK 1
-template <int KT, typename PRE, typename FIN>
+template <int KT, bool FROM_ZERO = true, typename PRE, typename FIN>
 __device__ __forceinline__ void gather_walk(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
                                             int K, int HV, int64_t beg, int64_t end, PRE&& pre, FIN&& finish) {
   int64_t e = beg + threadIdx.x;
@@ -68,7 +69,6 @@ __device__ __forceinline__ void gather_walk(const float* __restrict__ src, int64
   int64_t r = e / HV;
   int q = static_cast<int>(e - r * HV);
   int32_t j[KT], jn[KT];
-#pragma unroll
   for (int k = 0; k < KT; ++k) j[k] = idx[r * K + k];
   while (true) {
     int64_t rn = r + quo;
@@ -79,22 +79,18 @@ __device__ __forceinline__ void gather_walk(const float* __restrict__ src, int64
     }
     const bool more = e + 256 < end;
     const int32_t* irn = idx + (more ? rn : r) * K;     // (unconditional loads from a valid row)
-#pragma unroll
     for (int k = 0; k < KT; ++k) jn[k] = irn[k];
     const int c = q * 4;
     f32x4 v[KT];
-#pragma unroll
     for (int k = 0; k < KT; ++k) v[k] = ld<4>(j[k] >= 0 ? src + j[k] * ld_src + c : gather_zero);
     auto aux = pre(r, c);
-    f32x4 acc = f32x4(0.0f);
-#pragma unroll
-    for (int k = 0; k < KT; ++k) acc = acc + v[k];
+    f32x4 acc = FROM_ZERO ? f32x4(0.0f) + v[0] : v[0];  // (0 + v0 turns a -0.0 into +0.0, as the sum loop always did)
+    for (int k = 1; k < KT; ++k) acc = acc + v[k];
     finish(r, c, acc, aux);
     if (!more) break;
     e += 256;
     r = rn;
     q = qn;
-#pragma unroll
     for (int k = 0; k < KT; ++k) j[k] = jn[k];
   }
 }
@@ -431,6 +427,24 @@ __global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __rest
                                                              float* __restrict__ out, int64_t ld_out) {
   using V = typename Vec<VEC>::T;
   const int64_t total = n_out * HV;
+#ifdef RR_GATHER_WALK
+  if constexpr (VEC == 4) {
+    int64_t wbeg, wend;
+    gather_block_range(static_cast<int>(gridDim.x), total, &wbeg, &wend);
+    auto pre = [](int64_t, int) { return 0; };
+    auto fin = [&](int64_t r, int c, f32x4 v, int) {
+      if (thr != 0u) {                                  // H % 4 == 0 and c % 4 == 0: one aligned group of the mask stream
+        const uint64_t base = static_cast<uint64_t>(r) * static_cast<uint64_t>(H) + static_cast<uint64_t>(c);
+        const uint32_t w = rr_hash_group(seed, base >> 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = rr_hash_lane(w, q) >= thr ? v[q] * keep_scale : 0.f;
+      }
+      st<4>(out + r * ld_out + c, v);
+    };
+    gather_walk<1, false>(src, ld_src, idx, 1, HV, wbeg, wend, pre, fin);
+    return;
+  }
+#endif
   RR_GATHER_LOOP(e, static_cast<int>(gridDim.x), total) {
     const int64_t r = e / HV;
     const int c = static_cast<int>(e - r * HV) * VEC;
@@ -537,8 +551,29 @@ __global__ void __launch_bounds__(256) segment_mean_fwd_kernel(const float* __re
     float v;
     if (c < H) {
       const int32_t start = a_scope[2 * m], size = a_scope[2 * m + 1];
+      // the molecule's rows in groups of 8 independent loads, added in row order (a plain `acc += x[...]` loop over a
+      // run-time count is one memory round trip per atom: ~18 in a row per thread)
       float acc = 0.f;
-      for (int32_t i = 0; i < size; ++i) acc += x[(static_cast<int64_t>(start) + i) * ldx + c];
+      const float* p = x + static_cast<int64_t>(start) * ldx + c;
+      int32_t i = 0;
+      for (; i + 8 <= size; i += 8, p += 8 * ldx) {
+        const float l0 = p[0], l1 = p[ldx], l2 = p[2 * ldx], l3 = p[3 * ldx];
+        const float l4 = p[4 * ldx], l5 = p[5 * ldx], l6 = p[6 * ldx], l7 = p[7 * ldx];
+        acc = (((((((acc + l0) + l1) + l2) + l3) + l4) + l5) + l6) + l7;
+      }
+      if (i + 4 <= size) {
+        const float l0 = p[0], l1 = p[ldx], l2 = p[2 * ldx], l3 = p[3 * ldx];
+        acc = (((acc + l0) + l1) + l2) + l3;
+        i += 4;
+        p += 4 * ldx;
+      }
+      if (i < size) {                                   // 1..3 rows left: loads from clamped rows, adds by count
+        const int32_t n = size - i;
+        const float l0 = p[0], l1 = p[n > 1 ? ldx : 0], l2 = p[n > 2 ? 2 * ldx : 0];
+        acc += l0;
+        if (n > 1) acc += l1;
+        if (n > 2) acc += l2;
+      }
       v = size > 0 ? acc / static_cast<float>(size) : 0.f;
     } else {
       v = feat[m * F + (c - H)];

@@ -56,6 +56,31 @@ forms = {
     "atom <- atoms (a2a, K 4)": (lambda: Fn.gather_sum(atom, a2a, H, out=out_a), 4 * (2 * NA * H + 4 * NA)),
     "atom <- atoms (a2a, K 4), f32 mask": (lambda: Fn.gather_sum(atom, a2a, H, out=out_a, mask=y[:NA], mask_scale=1.1), 4 * (3 * NA * H + 4 * NA)),
 }
+# readout and the shared-prefix kernels
+class _G:
+    pass
+
+
+g = _G()
+g.M, g.nA = 4096, NA
+sizes = torch.full((g.M,), NA // g.M, dtype=torch.int32)
+sizes[: (NA - 1) - int(sizes.sum())] += 1
+starts = 1 + torch.cumsum(sizes, 0) - sizes
+g.a_scope = torch.stack([starts, sizes], 1).to(torch.int32).contiguous().to(dev)
+a2m = torch.full((NA,), -1, dtype=torch.int32)
+a2m[1:1 + int(sizes.sum())] = torch.repeat_interleave(torch.arange(g.M, dtype=torch.int32), sizes.long())
+g.atom2mol = a2m.to(dev)
+feat = torch.rand(g.M, 1, device=dev)
+dvec = torch.randn(g.M, 304, device=dev)[:, :301]
+ya = y[:NA]
+ya._rr_bits = bits[:NA]
+copies = (torch.arange(NB, device=dev) // 34 // 64 * 34 + torch.arange(NB, device=dev) % 34).clamp(max=2200).to(torch.int32)
+small = torch.randn(2201, H, device=dev)
+forms.update({
+    "readout: segment mean over ~17 atoms + feature, dropout": (lambda: Fn.segment_mean_fwd(atom, g, H, feat, 1, 0.1, 5), 4 * (NA * H + g.M * 301)),
+    "readout adjoint, sign-bit mask": (lambda: Fn.segment_mean_bwd(dvec, g, H, 1, 0.1, 5, mask=ya, mask_scale=1.1), 4 * (NA * H + g.M * 301) + NA * 40),
+    "bond <- distinct bond (1 source), dropout": (lambda: Fn.gather_dropout(small, copies, H, 0.1, 7), 4 * (NB * H + NB)),
+})
 tot = 0.0
 for name, (fn, nbytes) in forms.items():
     us = t(fn)
