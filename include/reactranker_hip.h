@@ -76,6 +76,14 @@ int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src,
 int rr_gather_sum_masked_f32(const float* src, const float* mask, int64_t n_src, int64_t ld_src,
                              const int32_t* idx, int64_t n_out, int K, int H, float scale,
                              float* out, int64_t ld_out, rr_stream_t stream);
+/* The same sum when the mask is dropout_j(y[r]) - the copies of a shared row, each with its own dropout mask, as
+ * rr_gather_dropout_f32(y, ..., drop_p, drop_seed) produced them:
+ *   out[r, c] = sum_k ( kept(drop_seed, j * H + c) && y[r, c] > 0 ? src[j, c] * scale : 0 ),  j = idx[r*K+k] >= 0
+ * Equal to rr_gather_sum_masked_f32 on the materialised copies bit for bit, without reading them (ABI revision 5).
+ * Needs H % 4 == 0 and 16-byte aligned rows (RR_ERR_ALIGN otherwise). */
+int rr_gather_sum_dropmask_f32(const float* src, int64_t n_src, int64_t ld_src, const float* y, int64_t ld_y,
+                               const int32_t* idx, int64_t n_out, int K, int H, float drop_p, uint64_t drop_seed,
+                               float scale, float* out, int64_t ld_out, rr_stream_t stream);
 
 /* Gather-sum with a fused epilogue - the form the backward chain uses (ABI revision 4):
  *   out[r, :] = M_r( sum_{k<K, idx[r*K+k] >= 0} src[idx[r*K+k], :] )  +  sum_{j<n_adds} adds[j][r, :]

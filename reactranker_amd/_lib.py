@@ -131,6 +131,7 @@ _SIGS = {
     "rr_segment_mean_bwd_masked_f32": (i32, [c_f32p, i64, c_i32p, c_i32p, i64, i32, i32, f32, u64, c_f32p, i64, C.c_void_p, f32,
                                              c_f32p, i64, c_stream]),
     "rr_gather_sum_masked_f32": (i32, [c_f32p, c_f32p, i64, i64, c_i32p, i64, i32, i32, f32, c_f32p, i64, c_stream]),
+    "rr_gather_sum_dropmask_f32": (i32, [c_f32p, i64, i64, c_f32p, i64, c_i32p, i64, i32, i32, f32, u64, f32, c_f32p, i64, c_stream]),
     "rr_gather_sum_csr_f32": (i32, [c_f32p, i64, i64, c_i32p, c_i32p, i64, i32, c_f32p, i64, c_stream]),
     "rr_build_fbonds_f32": (i32, [c_f32p, i64, i64, i32, c_i32p, c_f32p, i64, i32, i64, c_f32p, i64, c_stream]),
     "rr_gather_diff_f32": (i32, [c_f32p, i64, i64, c_i32p, c_f32p, i64, i64, c_i32p, i64, i32, c_f32p, i64, c_stream]),
@@ -194,7 +195,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

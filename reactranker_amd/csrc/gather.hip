@@ -139,6 +139,51 @@ __global__ void __launch_bounds__(256) gather_sum_masked_kernel(const float* __r
   }
 }
 
+// The same sum over the copies with the mask DERIVED instead of read: the copies' activations are
+// dropout_j(y[u]) (rr_gather_dropout_f32), so "activation of copy row j > 0" is "kept(j, c) and y[u, c] > 0" - the keep bit
+// comes out of the counter-based stream (element j * H + c, as the forward drew it), y is the small pre-dropout tensor of
+// the DESTINATION rows.  Same selects, same products, same order as gather_sum_masked_kernel on the materialised mask,
+// without reading that [n_src, H] tensor (half of the kernel's bytes).
+__global__ void __launch_bounds__(256) gather_sum_dropmask_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                                  const float* __restrict__ y, int64_t ld_y,
+                                                                  const int32_t* __restrict__ idx, int64_t n_out, int K, int HV,
+                                                                  int H, uint32_t thr, uint64_t seed, float scale,
+                                                                  float* __restrict__ out, int64_t ld_out) {
+  const int64_t total = n_out * HV;
+  RR_GATHER_LOOP(e, static_cast<int>(gridDim.x), total) {
+    const int64_t r = e / HV;
+    const int c = static_cast<int>(e - r * HV) * 4;
+    const int32_t* ir = idx + r * K;
+    const f32x4 yv = ld<4>(y + r * ld_y + c);
+    auto term = [&](int32_t j, f32x4 v) -> f32x4 {       // (mask > 0 ? v * scale : 0) per element
+      uint32_t w = 0u;
+      if (thr != 0u) w = rr_hash_group(seed, (static_cast<uint64_t>(j < 0 ? 0 : j) * static_cast<uint64_t>(H) + static_cast<uint64_t>(c)) >> 2);
+      f32x4 t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool keep = thr == 0u || rr_hash_lane(w, q) >= thr;
+        t[q] = (j >= 0 && keep && yv[q] > 0.f) ? v[q] * scale : 0.f;
+      }
+      return t;
+    };
+    f32x4 acc = f32x4(0.0f);
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {          // four row loads in flight; pad entries read the zero chunk
+      const int32_t j0 = ir[k], j1 = ir[k + 1], j2 = ir[k + 2], j3 = ir[k + 3];
+      const f32x4 v0 = ld<4>(j0 >= 0 ? src + j0 * ld_src + c : gather_zero);
+      const f32x4 v1 = ld<4>(j1 >= 0 ? src + j1 * ld_src + c : gather_zero);
+      const f32x4 v2 = ld<4>(j2 >= 0 ? src + j2 * ld_src + c : gather_zero);
+      const f32x4 v3 = ld<4>(j3 >= 0 ? src + j3 * ld_src + c : gather_zero);
+      acc = (((acc + term(j0, v0)) + term(j1, v1)) + term(j2, v2)) + term(j3, v3);
+    }
+    for (; k < K; ++k) {
+      const int32_t j = ir[k];
+      acc = acc + term(j, ld<4>(j >= 0 ? src + j * ld_src + c : gather_zero));
+    }
+    st<4>(out + r * ld_out + c, acc);
+  }
+}
+
 template <int VEC>
 __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict__ src, int64_t ld_src,
                                                          const int32_t* __restrict__ idx, int64_t n_out, int K,
@@ -756,6 +801,19 @@ int rr_gather_sum_masked_f32(const float* src, const float* mask, int64_t n_src,
     gather_sum_masked_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, mask, ld_src, idx, n_out, K, H, scale, out,
                                                                             ld_out);
   }
+  return rr_launch_status();
+}
+
+int rr_gather_sum_dropmask_f32(const float* src, int64_t n_src, int64_t ld_src, const float* y, int64_t ld_y,
+                               const int32_t* idx, int64_t n_out, int K, int H, float drop_p, uint64_t drop_seed, float scale,
+                               float* out, int64_t ld_out, rr_stream_t stream) {
+  RR_CHECK_ARG(src && y && idx && out && n_src >= 0 && n_out >= 1 && K >= 1 && H >= 1 && ld_src >= H && ld_y >= H && ld_out >= H);
+  RR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  if (!(H % 4 == 0 && ld_src % 4 == 0 && ld_y % 4 == 0 && ld_out % 4 == 0 && rr_aligned16(src) && rr_aligned16(y) && rr_aligned16(out)))
+    return RR_ERR_ALIGN;                                // (the dropout stream is hashed per aligned group of four elements)
+  const int HV = H / 4;
+  gather_sum_dropmask_kernel<<<rr_grid_for(n_out * HV, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      src, ld_src, y, ld_y, idx, n_out, K, HV, H, rr_drop_threshold(drop_p), drop_seed, scale, out, ld_out);
   return rr_launch_status();
 }
 

@@ -206,6 +206,8 @@ struct EncSaved {                    // mpn_forward / mpn_forward_shared
   float* a_last;
   float* h;                          // [nA, H] atom hiddens (output)
   float *msg0_u, *a0_u;              // shared prefix (distinct molecules)
+  float* z1_u;                       // ... its pre-dropout output, and the stream the copies' masks were drawn from
+  uint64_t seed0;
 };
 struct DiffSaved {
   uint8_t* bits[MAXD];
@@ -298,6 +300,8 @@ void mpn_forward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_
   S.msgs[0] = nullptr;
   S.msgs[1] = c.ar.f(g.nB, H);
   RR_TRY(c, rr_gather_dropout_f32(z1_u, gu.nB, H, bmap, g.nB, H, p, site_seed(seed, 0), S.msgs[1], H, st));   // per-copy masks
+  S.z1_u = z1_u;
+  S.seed0 = site_seed(seed, 0);
   for (int it = 1; it < depth - 1; ++it) {
     S.amsgs[it] = c.ar.f(g.nA, H);
     gather_sum(c, S.msgs[it], g.nB, H, g.a2b, g.nA, g.K, H, S.amsgs[it], H, st);
@@ -552,9 +556,13 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
                S.bits[it], ks, nullptr, 0);
   }
   // ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
-  // dz1 of every copy is read once, by the sum over the copies: mask and gather in one pass (no [nB, H] round trip)
+  // dz1 of every copy is read once, by the sum over the copies: mask and gather in one pass (no [nB, H] round trip), the
+  // copies' masks re-derived from the dropout stream and z1_u instead of read back from msgs[1]
   float* dz1_u = c.ar.f(gu.nB, H);
-  RR_TRY(c, rr_gather_sum_masked_f32(d_msg, S.msgs[1], g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, ks, dz1_u, H, st));
+  if (H % 4 == 0)
+    RR_TRY(c, rr_gather_sum_dropmask_f32(d_msg, g.nB, H, S.z1_u, H, bmap_t, gu.nB, bmap_t_cols, H, p, S.seed0, ks, dz1_u, H, st));
+  else
+    RR_TRY(c, rr_gather_sum_masked_f32(d_msg, S.msgs[1], g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, ks, dz1_u, H, st));
   float* d_inp_u = c.ar.f(gu.nB, H);
   if (have_full) {
     gather_sum(c, d_inp_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, d_inp_u, H, st);

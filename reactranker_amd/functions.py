@@ -147,6 +147,20 @@ def gather_sum_masked(src, mask, scale: float, idx, H: int, out=None):
     return out
 
 
+def gather_sum_dropmask(src, y, scale: float, idx, H: int, p: float, seed: int, out=None):
+    """gather_sum_masked(src, gather_dropout(y, copies, H, p, seed), scale, idx, H) without the materialised copies: the keep
+    bits come from the dropout stream, the sign from `y` (the pre-dropout activations of the DESTINATION rows); bit-identical."""
+    n_out, K = idx.shape
+    if out is None:
+        out = _new(src, n_out, H)
+    assert y.shape[0] == n_out
+    with _Timed("gather_sum_dropmask_kernel", 0, 4 * (src.shape[0] * H + 2 * n_out * H + n_out * K)):
+        check(lib().rr_gather_sum_dropmask_f32(ptr(src), src.shape[0], _ld(src), ptr(y), _ld(y), ptr(idx), n_out, K, H, float(p),
+                                               int(seed) & 0xFFFFFFFFFFFFFFFF, float(scale), ptr(out), _ld(out), stream()),
+              "rr_gather_sum_dropmask_f32")
+    return out
+
+
 def gather_sum_csr(src: torch.Tensor, offsets: torch.Tensor, idx: torch.Tensor, n_out: int, H: int) -> torch.Tensor:
     """out[r] = sum of src[idx[j]] for j in [offsets[r], offsets[r+1]) — adjoint of a gather through a generic index."""
     out = _new(src, n_out, H)
@@ -629,7 +643,7 @@ def mpn_forward_shared(gu, g, bmap, H: int, depth: int, Wi: LinW, Wh: LinW, Wo: 
     a_last = gather_sum(msgs[-1], g.a2b, H)
     h = linear(nA, H, Wo.pk(ATOM_FDIM, H), w_packed=True, a1=g.f_atoms, k1=ATOM_FDIM, a2=a_last, k2=H, bias=Wo.b,
                act=ACT_RELU, drop_p=p, seed=_site_seed(seed, 1000), want_bits=True)
-    return h, (msgs, amsgs, a_last, h, (msg0_u, a0_u))
+    return h, (msgs, amsgs, a_last, h, (msg0_u, a0_u, z1_u, _site_seed(seed, 0)))
 
 
 def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, Wo: LinW, p: float, saved, dH, sign: float,
@@ -638,7 +652,7 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
     the shared prefix are summed over the copies (fixed-order segment sums over `bmap_t`) and the prefix is
     back-propagated once on the distinct molecules — every op there is linear in the gradient, so the sum
     commutes with it."""
-    msgs, amsgs, a_last, h, (msg0_u, a0_u) = saved
+    msgs, amsgs, a_last, h, (msg0_u, a0_u, z1_u, seed0) = saved
     nA, nB, nBu = g.nA, g.nB, gu.nB
     ks = 1.0 / (1.0 - p)
     acc0 = into is not None                                          # see mpn_backward
@@ -667,7 +681,12 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
         d_inp_full = dz if d_inp_full is None else axpby(1.0, d_inp_full, 1.0, dz)   # fresh buffer (side-stream readers)
         d_msg = bond_message_adjoint(d_min, g, H, part, mask=(msgs[it] if it - 1 >= 1 else None), mask_scale=ks)
     # ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
-    dz1_u = gather_sum_masked(d_msg, msgs[1], ks, bmap_t, H)          # (msgs[1] > 0) <=> kept and z1 > 0; sum over the copies
+    # (msgs[1] > 0) <=> kept and z1 > 0: mask and sum over the copies in one pass, the copies' masks re-derived from the
+    # dropout stream instead of read (rows need 16-byte chunks: H % 4 == 0, else the materialised-mask form)
+    if H % 4 == 0:
+        dz1_u = gather_sum_dropmask(d_msg, z1_u, ks, bmap_t, H, p, seed0)
+    else:
+        dz1_u = gather_sum_masked(d_msg, msgs[1], ks, bmap_t, H)
     if d_inp_full is not None:
         d_inp_u = gather_sum(d_inp_full, bmap_t, H)
         axpby(1.0, d_inp_u, 1.0, dz1_u, out=d_inp_u)

@@ -331,6 +331,34 @@ def test_gather_sum_masked_equals_relu_backward_then_gather(H, K):
     close(got, want, what="masked gather")
 
 
+@pytest.mark.parametrize("H,p", [(300, 0.1), (300, 0.0), (64, 0.35), (600, 0.2)])
+@pytest.mark.parametrize("copies", [1, 5, 64])
+def test_gather_sum_with_derived_dropout_mask_equals_the_materialised_mask(H, p, copies):
+    """rr_gather_sum_dropmask_f32 (shared-prefix backward: the copies' masks re-derived from the dropout stream and the small
+    pre-dropout tensor) against rr_gather_sum_masked_f32 on the copies rr_gather_dropout_f32 actually produced: torch.equal,
+    incl. destinations with fewer copies than the table is wide and one with none."""
+    rng = np.random.default_rng(H + copies)
+    n_u, seed = 41, 0x1234ABCD5678
+    n_full = n_u * copies + 1
+    y = dev(np.maximum(rng.standard_normal((n_u, H)), 0).astype(np.float32))                # relu output of the shared layer
+    owner = rng.integers(0, n_u, size=n_full).astype(np.int32)                               # full row -> distinct row
+    owner[owner == 7] = 8                                                                    # row 7 has no copies
+    full = Fn.gather_dropout(y, dev(owner), H, p, seed)                                      # what the forward materialises
+    table = np.full((n_u, max(1, int(np.bincount(owner, minlength=n_u).max()))), -1, np.int32)
+    fill = np.zeros(n_u, np.int64)
+    for j, u in enumerate(owner):
+        table[u, fill[u]] = j
+        fill[u] += 1
+    src = dev(rng.standard_normal((n_full, H)).astype(np.float32))
+    ks = 1.0 / (1.0 - p)
+    ref = Fn.gather_sum_masked(src, full, ks, dev(table), H)
+    got = Fn.gather_sum_dropmask(src, y, ks, dev(table), H, p, seed)
+    assert torch.equal(got, ref)
+    assert float(got[7].abs().max()) == 0.0
+    if p > 0:
+        assert not torch.equal(got, Fn.gather_sum_dropmask(src, y, ks, dev(table), H, p, seed + 1))   # the stream matters
+
+
 @pytest.mark.parametrize("H,F,p", [(300, 1, 0.1), (300, 0, 0.0), (32, 1, 0.3), (30, 1, 0.2)])
 def test_segment_mean_backward_is_the_adjoint_with_the_forward_dropout_stream(H, F, p):
     """Readout (models/mpn.py:224-238): dx[a] = dout[mol(a)] / size * keep / (1 - p), keep taken from the SAME counter-based
