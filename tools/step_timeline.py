@@ -1,5 +1,6 @@
 """Per-stream kernel sequence of ONE training step from a rocprofv3 --kernel-trace CSV (start offset, duration, name),
-plus per-stream busy time.  Usage: python tools/step_timeline.py <kernel_trace.csv> [step_from_end=2] [--brief]"""
+plus per-stream busy time.  Usage: python tools/step_timeline.py <kernel_trace.csv> [step_from_end=2] [--brief] [--marks-per-step N]
+(N = 2 for losses whose forward and backward are the same kernel symbol: ListNet, evidential)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 2
@@ -10,6 +11,8 @@ for r in rows:
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, r.get("Stream_Id") or r.get("Queue_Id")))
 ev.sort()
 marks = [e[0] for e in ev if "listmle_fwd" in e[2] or "listnet_kernel" in e[2] or "ranknet_fwd" in e[2] or "evidential_kernel" in e[2]]
+if "--marks-per-step" in sys.argv:
+    marks = marks[::int(sys.argv[sys.argv.index("--marks-per-step") + 1])]
 lo, hi = marks[-1 - back], marks[-back]
 print(f"step window {(hi - lo) / 1e6:.3f} ms")
 streams = {}
