@@ -389,17 +389,29 @@ int rr_gauss_nll_bwd_f32(const float* mean, const float* var, int64_t stride, co
                          int64_t n, const float* gloss, float* dmean, float* dvar, int64_t dstride,
                          rr_stream_t stream);
 
-/* Per-query ranking evaluation on the device — `ranking_metrics` (train/eval.py:475-555) without the
- * one-forward-per-query loop and the Python lists; same list description as the losses.
+/* Per-query ranking evaluation on the device - the metric halves of `ranking_metrics` (train/eval.py:475-555),
+ * `evaluate_top_scores` (:76-177) and `calculate_ndcg` (:329-457) without the one-forward-per-query loops and the
+ * Python lists; same list description as the losses.  ABI revision 6: `ratio`, `ndcg_cut`, 12 statistics per query.
  *   order[off_q + r] = position (inside its list) of the candidate ranked r-th by score, descending, ties
  *                      keeping the original order (python's stable sorted(..., reverse=True), :516-519)
- *   stats[q*8 + 0..7] = { top-1 hit, top-25% hit, recall@25%, NDCG1, NDCG2, NDCG25%, NDCG_all   (:521-546,
- *                         exp gains, compute_NDCG :460-472, python round() for the 25% cut, NDCG2 without
- *                         discount exactly as the reference computes it),
- *                         NDCG@10 with exp2 gains of `targets` taken as relevance grades (metrics.py:54-71) }
- * stats are float64.  The trainer-level numbers are the means over queries. */
+ *   stats[q*RR_RANKING_NSTATS + 0..11], float64:
+ *     0..6  ranking_metrics: top-1 hit, PREDICTED top-1 in the target top-25%, recall@25%, NDCG1, NDCG2, NDCG25%,
+ *           NDCG_all (:521-546; exp gains, compute_NDCG :460-472, python round() for the 25% cut, NDCG2 without
+ *           discount exactly as the reference computes it)
+ *     7     NDCG@10 with exp2 gains of `targets` taken as relevance grades (metrics.py:54-71)
+ *     8     evaluate_top_scores' third value: the TARGET's top-1 (first maximum, :133) in the predicted
+ *           top-round(C*ratio) (:144-146, :156-159) - not the same quantity as stat 1
+ *     9     calculate_ndcg's NDCG: gains C + 1 - predicted rank over the first ceil(C*ndcg_cut) positions of the
+ *           target order (:406-425, cal_NDCG :309-325); ties by position (the reference's torch.sort leaves them open)
+ *     10    calculate_ndcg's KL(softmax(targets) || softmax(score)) with un-shifted f32 exponentials (:401-404)
+ *     11    evaluate_top_scores' second value: share of the predicted top-round(C*ratio) inside the target
+ *           top-round(C*ratio) (:147-151); equals stat 2 at ratio = 0.25
+ *   evaluate_top_scores' first value (first-maximum top-1, :133-136) is stat 0.
+ * 0 <= ratio, ndcg_cut <= 1.  The trainer-level numbers are the means over queries. */
+#define RR_RANKING_NSTATS 12
 int rr_ranking_metrics_f32(const float* score, int64_t score_stride, const float* targets, const int32_t* seg_off,
-                           int Q, int max_len, int32_t* order, double* stats, rr_stream_t stream);
+                           int Q, int max_len, double ratio, double ndcg_cut, int32_t* order, double* stats,
+                           rr_stream_t stream);
 
 /* LogCumsumExp along dim 0 of a 1-D tensor (train/loss.py:9-61); n <= 8192.
  * backward keeps the reference's un-shifted exp(x) (:59). */
@@ -506,6 +518,23 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step);
 int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, rr_stream_t stream);
 int rr_reaction_backward(const rr_model* model, const rr_step* step, const float* dout, const rr_grads* grads, int flags,
                          rr_stream_t stream);
+
+/* Where a step keeps an activation inside its workspace (ABI revision 6) - valid from rr_reaction_forward until the
+ * workspace is reused; nothing is launched.  For hosts that want the encoder's outputs (atom hiddens, reaction vectors:
+ * `return_atom_hiddens` / `vecs` of models/mpn.py:61-108, 224-238) without a second forward, and for tests that need the
+ * ReLU gates this arithmetic took.  `flags` as passed to rr_reaction_forward.  *ptr = NULL when the step has no such tensor
+ * (e.g. RR_SAVED_R_MSG index 0 in RR_STEP_PREFIX mode, where the first message exists per DISTINCT reactant only). */
+enum { RR_SAVED_R_MSG = 0,    /* reactant encoder: message after iteration `index` (0 = relu(W_i f_bonds)) [r.nB, H], post-dropout */
+       RR_SAVED_R_H = 1,      /* reactant atom hiddens [r.nA, H] */
+       RR_SAVED_P_MSG = 2, RR_SAVED_P_H = 3,            /* the same for the product encoder */
+       RR_SAVED_D_MSG = 4,    /* diff encoder: message after iteration `index` [p.nA, H] */
+       RR_SAVED_D_HID = 5,    /* diff encoder atom hiddens [p.nA, H] */
+       RR_SAVED_VECS = 6,     /* readout + add_features (after the FFN's input dropout) [M, ld] */
+       RR_SAVED_FFN_H = 7,    /* FFN hidden layer `index` (1 .. n_ffn-1) [M, ld] */
+       RR_SAVED_R_MSG0_U = 8, /* RR_STEP_PREFIX: relu(W_i f_bonds) of the distinct reactants [u.nB, H] */
+       RR_SAVED_R_Z1_U = 9 }; /* RR_STEP_PREFIX: their first W_h layer before dropout [u.nB, H] */
+int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags, int which, int index,
+                          const float** ptr, int64_t* rows, int64_t* ld);
 
 /* ------------------------------------------------------------------ data-parallel gradient exchange (RCCL) --- */
 /* Queries are independent: one process per GPU, whole queries per rank, identical replicas, and ONE sum all-reduce of the

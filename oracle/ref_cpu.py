@@ -142,22 +142,33 @@ def _drop(x, masks, key, p):
     return x * masks[key] / (1.0 - p)
 
 
-def mpn_forward(P, g, depth, prefix="encoder", masks=None, p=0.0, tag="r"):
+def _relu(x, key, gates=None, trace=None):
+    """torch.relu - or, for the gate-attribution tests, the same layer with its gates dictated from outside:
+    `gates[key]` (0/1, same shape) replaces the sign test, so a pre-activation within rounding of zero opens exactly
+    where the arithmetic under test opened it.  `trace[key]` records the pre-activation."""
+    if trace is not None:
+        trace[key] = x.detach()
+    if gates is not None and key in gates:
+        return x * gates[key].to(x.dtype)
+    return torch.relu(x)
+
+
+def mpn_forward(P, g, depth, prefix="encoder", masks=None, p=0.0, tag="r", gates=None, trace=None):
     """MPN.forward with return_atom_hiddens=True (models/mpn.py:61-108)."""
     f_atoms, f_bonds = g["f_atoms"], g["f_bonds"]
     a2b, b2a, b2revb = g["a2b"], g["b2a"], g["b2revb"]
     inp = _linear(P, prefix + ".W_i", f_bonds)                              # :80
-    message = torch.relu(inp)                                              # :81
+    message = _relu(inp, f"{tag}.enc.in", gates, trace)                    # :81
     for it in range(depth - 1):                                            # :84
         a_message = index_select_nd(message, a2b).sum(dim=1)               # :89-90
         rev_message = message[b2revb]                                      # :91
         message = a_message[b2a] - rev_message                             # :92
         message = _linear(P, prefix + ".W_h", message)                     # :94
-        message = torch.relu(inp + message)                                # :95
+        message = _relu(inp + message, f"{tag}.enc.{it}", gates, trace)    # :95
         message = _drop(message, masks, f"{tag}.enc.{it}", p)              # :97
     a_message = index_select_nd(message, a2b).sum(dim=1)                   # :101-102
     a_input = torch.cat([f_atoms, a_message], dim=1)                       # :103
-    atom_hiddens = torch.relu(_linear(P, prefix + ".W_o", a_input))        # :104
+    atom_hiddens = _relu(_linear(P, prefix + ".W_o", a_input), f"{tag}.enc.out", gates, trace)   # :104
     return _drop(atom_hiddens, masks, f"{tag}.enc.out", p)                 # :105
 
 
@@ -181,22 +192,22 @@ def readout_mean(atom_hiddens, a_scope, faithful):
 
 
 def mpn_diff_forward(P, atom_features, g, depth, features_batch=None, prefix="diff_encoder",
-                     masks=None, p=0.0, faithful=False):
+                     masks=None, p=0.0, faithful=False, gates=None, trace=None):
     """MPNDiff.forward (models/mpn.py:170-240); bond_fdim = 83 so the slice :206 keeps every column."""
     f_bonds, a2b, a2a = g["f_bonds"], g["a2b"], g["a2a"]
     inp = _linear(P, prefix + ".W_i", atom_features)                       # :194
-    message = torch.relu(inp)                                              # :195
+    message = _relu(inp, "diff.in", gates, trace)                          # :195
     if depth > 0:
         for it in range(depth - 1):                                        # :199
             nei_a = index_select_nd(message, a2a)                          # :201
             nei_fb = index_select_nd(f_bonds, a2b)                         # :202,206
             message = torch.cat((nei_a, nei_fb), dim=2).sum(dim=1)         # :208-209
             message = _linear(P, prefix + ".W_h", message)                 # :211
-            message = torch.relu(inp + message)                            # :212
+            message = _relu(inp + message, f"diff.{it}", gates, trace)     # :212
             message = _drop(message, masks, f"diff.{it}", p)               # :213
         a_message = index_select_nd(message, a2a).sum(dim=1)               # :215-216
         a_input = torch.cat([atom_features, a_message], dim=1)             # :217
-        atom_hiddens = torch.relu(_linear(P, prefix + ".W_o", a_input))    # :218
+        atom_hiddens = _relu(_linear(P, prefix + ".W_o", a_input), "diff.out", gates, trace)   # :218
         atom_hiddens = _drop(atom_hiddens, masks, "diff.out", p)           # :219
     else:
         atom_hiddens = _drop(message, masks, "diff.out", p)                # :221
@@ -210,7 +221,7 @@ def softplus(x):
     return F.softplus(x)      # torch.nn.Softplus(): beta=1, threshold=20
 
 
-def ffn_forward(P, x, ffn_depth, task_type, masks=None, p=0.0):
+def ffn_forward(P, x, ffn_depth, task_type, masks=None, p=0.0, gates=None, trace=None):
     """FFN.forward (models/base_model.py:59-108): Dropout before every Linear, ReLU between."""
     h = _drop(x, masks, "ffn.0", p)
     if ffn_depth == 1:
@@ -219,10 +230,10 @@ def ffn_forward(P, x, ffn_depth, task_type, masks=None, p=0.0):
         h = _linear(P, "ffn.ffn.1", h)
         idx = 4
         for li in range(ffn_depth - 2):
-            h = _drop(torch.relu(h), masks, f"ffn.{li + 1}", p)
+            h = _drop(_relu(h, f"ffn.{li + 1}", gates, trace), masks, f"ffn.{li + 1}", p)
             h = _linear(P, f"ffn.ffn.{idx}", h)
             idx += 3
-        h = _drop(torch.relu(h), masks, f"ffn.{ffn_depth - 1}", p)
+        h = _drop(_relu(h, f"ffn.{ffn_depth - 1}", gates, trace), masks, f"ffn.{ffn_depth - 1}", p)
         out = _linear(P, f"ffn.ffn.{idx}", h)
     out = out.squeeze(-1)                                                  # :60
     mv = 1e-6
@@ -256,16 +267,17 @@ def graph_tensors(g: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
 
 
 def reaction_forward(P, cfg, r_graph, p_graph, add_features=None, masks=None, faithful=False,
-                     return_parts=False):
+                     return_parts=False, gates=None, trace=None):
     """ReactionModel.forward (models/base_model.py:150-171).
 
     cfg keys: depth, diff_depth, ffn_depth, task_type (already resolved), dropout.
+    gates / trace: see _relu (keys `{r,p}.enc.{in,0..,out}`, `diff.{in,0..,out}`, `ffn.{1..}`).
     """
     p = float(cfg.get("dropout", 0.0)) if masks is not None else 0.0
     r = graph_tensors(r_graph) if not torch.is_tensor(r_graph["f_atoms"]) else r_graph
     pg = graph_tensors(p_graph) if not torch.is_tensor(p_graph["f_atoms"]) else p_graph
-    r_h = mpn_forward(P, r, cfg["depth"], masks=masks, p=p, tag="r")       # :155
-    p_h = mpn_forward(P, pg, cfg["depth"], masks=masks, p=p, tag="p")      # :156
+    r_h = mpn_forward(P, r, cfg["depth"], masks=masks, p=p, tag="r", gates=gates, trace=trace)       # :155
+    p_h = mpn_forward(P, pg, cfg["depth"], masks=masks, p=p, tag="p", gates=gates, trace=trace)      # :156
     diff = p_h - r_h                                                       # :168
     if add_features is None:
         fb = None
@@ -273,8 +285,8 @@ def reaction_forward(P, cfg, r_graph, p_graph, add_features=None, masks=None, fa
         fb = add_features                                    # caller chose the dtype (fp64 identity checks)
     else:
         fb = _t(np.asarray(add_features), torch.float32)
-    vecs = mpn_diff_forward(P, diff, pg, cfg["diff_depth"], fb, masks=masks, p=p, faithful=faithful)
-    out = ffn_forward(P, vecs, cfg["ffn_depth"], cfg["task_type"], masks=masks, p=p)   # :169
+    vecs = mpn_diff_forward(P, diff, pg, cfg["diff_depth"], fb, masks=masks, p=p, faithful=faithful, gates=gates, trace=trace)
+    out = ffn_forward(P, vecs, cfg["ffn_depth"], cfg["task_type"], masks=masks, p=p, gates=gates, trace=trace)   # :169
     if return_parts:
         return out, dict(r_h=r_h, p_h=p_h, diff=diff, vecs=vecs)
     return out
@@ -443,6 +455,62 @@ def ranking_metrics_from_scores(scores_per_query, targets_per_query):
                    compute_ndcg_eval(tsorted[:len25], prt[:len25]), compute_ndcg_eval(tsorted, prt)])
     q = len(orders)
     return top1 / q, float(np.mean(recall)), top25 / q, np.mean(nd, axis=0), orders
+
+
+def top_scores_from_scores(scores_per_query, targets_per_query, ratio=0.25):
+    """evaluate_top_scores (train/eval.py:76-177) on given per-query scores: returns (average_score,
+    average_pred_in_targ, average_top1_in_pred) plus the per-query triples.  First-maximum top-1 (:133), python
+    round() for the cut (:144-146), and - unlike ranking_metrics' third value - the TARGET's top-1 looked up in the
+    PREDICTED top-`ratio` (:156-159)."""
+    rows = []
+    for pred, targ in zip(scores_per_query, targets_per_query):
+        batch_preds, batch_targets = [float(x) for x in pred], [float(x) for x in targ]
+        top1 = 1 if batch_targets.index(max(batch_targets)) == batch_preds.index(max(batch_preds)) else 0
+        idx1 = [a for a, _ in sorted(enumerate(batch_targets), key=lambda x: x[1], reverse=True)]
+        idx2 = [a for a, _ in sorted(enumerate(batch_preds), key=lambda x: x[1], reverse=True)]
+        length = round(len(batch_preds) * ratio)
+        if length == 0:
+            length = 1
+        num = sum(1 for i in range(length) if idx2[i] in idx1[:length])
+        t1 = 1 if batch_targets.index(max(batch_targets)) in idx2[:length] else 0
+        rows.append((top1, num / length, t1))
+    m = np.asarray(rows, np.float64)
+    return float(m[:, 0].mean()), float(m[:, 1].mean()), float(m[:, 2].mean()), m
+
+
+def cal_ndcg(preds: torch.Tensor, targets: torch.Tensor, n: int):
+    """train/eval.py:309-325 (cal_NDCG): linear gains, log2 discount, both truncated at n."""
+    targets, preds = targets[:n], preds[:n]
+    idcg = torch.sum(targets / torch.log2(torch.arange(targets.size(0), dtype=torch.float32) + 2))
+    dcg_n = torch.sum(preds / torch.log2(torch.arange(preds.size(0), dtype=torch.float32) + 2))
+    return dcg_n / idcg
+
+
+def calculate_ndcg_from_scores(scores_per_query, targets_per_query, ndcg_cut=0.5, means=None, stds=None):
+    """calculate_ndcg, is_order branch (train/eval.py:329-457) on given per-query scores (the first column of a 2-D
+    output, :390-396, after the optional de-standardisation :379-388).  Returns (NDCG_mean, KL_mean, per-query rows
+    [NDCG, KL]).  Rank-derived gains `length + 1 - order`, truncated at ceil(length * cut) positions of the TARGET
+    order (:421-425); KL(softmax(targets) || softmax(preds)) with un-shifted exponentials (:401-404).  Ties are broken
+    by position (a stable sort); torch.sort / argsort in the reference leave that open."""
+    import math
+    rows = []
+    for pred, targ in zip(scores_per_query, targets_per_query):
+        bp = torch.as_tensor(np.asarray(pred), dtype=torch.float32)
+        bt = torch.as_tensor(np.asarray(targ), dtype=torch.float32)
+        if means is not None:
+            bp = (bp * stds) + means
+        P = torch.exp(bt) / torch.sum(torch.exp(bt))
+        Qd = torch.exp(bp) / torch.sum(torch.exp(bp))
+        kl = torch.sum(P * torch.log(P / Qd))
+        _, idx = torch.sort(bt, descending=True, stable=True)
+        sorted_preds = bp[idx]
+        pred_order = torch.argsort(torch.argsort(sorted_preds, descending=True, stable=True), stable=True) + 1
+        length = bt.size(0)
+        true_order = torch.arange(length, dtype=torch.float32) + 1
+        nd = cal_ndcg(float(length + 1) - pred_order.float(), float(length + 1) - true_order, math.ceil(length * ndcg_cut))
+        rows.append((float(nd), float(kl)))
+    m = np.asarray(rows, np.float64)
+    return float(m[:, 0].mean()), float(m[:, 1].mean()), m
 
 
 def params_from_numpy(w: Dict[str, np.ndarray], requires_grad=False) -> Dict[str, torch.Tensor]:

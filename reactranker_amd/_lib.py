@@ -171,7 +171,8 @@ _SIGS = {
     "rr_mse_bwd_f32": (i32, [c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, i64, c_stream]),
     "rr_gauss_nll_fwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, c_stream]),
     "rr_gauss_nll_bwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
-    "rr_ranking_metrics_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, c_i32p, C.c_void_p, c_stream]),
+    "rr_ranking_metrics_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, C.c_double, C.c_double, c_i32p, C.c_void_p,
+                               c_stream]),
     "rr_logcumsumexp_fwd_f32": (i32, [c_f32p, i32, c_f32p, c_stream]),
     "rr_logcumsumexp_bwd_f32": (i32, [c_f32p, c_f32p, c_f32p, i32, c_f32p, c_stream]),
     "rr_pack_sizes": (i32, [C.c_void_p, C.c_void_p, i64, C.c_void_p, i32, C.POINTER(i64), C.POINTER(i64),
@@ -184,6 +185,8 @@ _SIGS = {
     "rr_reaction_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(Step)]),
     "rr_reaction_forward": (i32, [C.POINTER(Model), C.POINTER(Step), i32, c_stream]),
     "rr_reaction_backward": (i32, [C.POINTER(Model), C.POINTER(Step), c_f32p, C.POINTER(Grads), i32, c_stream]),
+    "rr_reaction_saved_f32": (i32, [C.POINTER(Model), C.POINTER(Step), i32, i32, i32, C.POINTER(C.c_void_p), C.POINTER(i64),
+                                    C.POINTER(i64)]),
     "rr_comm_unique_id": (i32, [C.c_void_p]),
     "rr_comm_init_rank": (i32, [C.POINTER(C.c_void_p), i32, C.c_void_p, i32]),
     "rr_comm_destroy": (i32, [C.c_void_p]),
@@ -195,7 +198,9 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
-ABI_VERSION = 5
+ABI_VERSION = 6
+(RR_SAVED_R_MSG, RR_SAVED_R_H, RR_SAVED_P_MSG, RR_SAVED_P_H, RR_SAVED_D_MSG, RR_SAVED_D_HID, RR_SAVED_VECS, RR_SAVED_FFN_H,
+ RR_SAVED_R_MSG0_U, RR_SAVED_R_Z1_U) = range(10)
 
 _lib = None
 

@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int kMaxLen = 8192;
+static_assert(kMaxLen <= 65536, "ranking_metrics_kernel keeps list positions in 16 bits");
 
 __device__ inline void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -440,20 +441,23 @@ __device__ inline double wave_sum_f64(double v) {
 __global__ void __launch_bounds__(RR_WAVE) ranking_metrics_kernel(const float* __restrict__ score, int64_t sstride,
                                                                   const float* __restrict__ targets,
                                                                   const int32_t* __restrict__ seg_off, int L,
+                                                                  double ratio, double ndcg_cut,
                                                                   int32_t* __restrict__ order,
                                                                   double* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int q = blockIdx.x, lane = threadIdx.x;
   const int off = seg_off[q], C = seg_off[q + 1] - off;
-  double* st = stats + static_cast<int64_t>(q) * 8;
+  double* st = stats + static_cast<int64_t>(q) * RR_RANKING_NSTATS;
   if (C <= 0) {
-    if (lane < 8) st[lane] = 0.0;
+    if (lane < RR_RANKING_NSTATS) st[lane] = 0.0;
     return;
   }
   float* s = sm;
   float* t = sm + L;
-  int32_t* po = reinterpret_cast<int32_t*>(sm + 2 * L);      // predicted order
-  int32_t* to = reinterpret_cast<int32_t*>(sm + 3 * L);      // target order
+  uint16_t* po = reinterpret_cast<uint16_t*>(sm + 2 * L);    // predicted order (list positions < 8192 fit 16 bits)
+  uint16_t* to = po + L;                                     // target order
+  uint16_t* pr = to + L;                                     // predicted rank of every candidate (inverse of po)
+  uint16_t* tr = pr + L;                                     // target rank of every candidate (inverse of to)
   for (int i = lane; i < C; i += RR_WAVE) {
     s[i] = score[static_cast<int64_t>(off + i) * sstride];
     t[i] = targets[off + i];
@@ -467,8 +471,10 @@ __global__ void __launch_bounds__(RR_WAVE) ranking_metrics_kernel(const float* _
       rp += (sj > si || (sj == si && j < i)) ? 1 : 0;
       rt += (tj > ti || (tj == ti && j < i)) ? 1 : 0;
     }
-    po[rp] = i;
-    to[rt] = i;
+    po[rp] = static_cast<uint16_t>(i);
+    to[rt] = static_cast<uint16_t>(i);
+    pr[i] = static_cast<uint16_t>(rp);
+    tr[i] = static_cast<uint16_t>(rt);
   }
   wave_sync();
   for (int r = lane; r < C; r += RR_WAVE) order[off + r] = po[r];
@@ -501,7 +507,54 @@ __global__ void __launch_bounds__(RR_WAVE) ranking_metrics_kernel(const float* _
   d25 = wave_sum_f64(d25); i25 = wave_sum_f64(i25);
   dall = wave_sum_f64(dall); iall = wave_sum_f64(iall);
   d10 = wave_sum_f64(d10); i10 = wave_sum_f64(i10);
+  // evaluate_top_scores (eval.py:76-177) at its `ratio`: cut = python round(C * ratio), at least 1 (:144-146);
+  // recall of the predicted top-cut in the target top-cut (:147-151) and the TARGET's first maximum looked up in the
+  // predicted top-cut (:156-159).  The first maximum (list.index(max)) is rank 0 of the stable descending order.
+  int lenr = static_cast<int>(rint(static_cast<double>(C) * ratio));
+  if (lenr < 1) lenr = 1;
+  if (lenr > C) lenr = C;
+  int hitr = 0;
+  for (int i = lane; i < lenr; i += RR_WAVE) {
+    const int pi = po[i];
+    int in = 0;
+    for (int j = 0; j < lenr; ++j) in |= (to[j] == pi) ? 1 : 0;
+    hitr += in;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) hitr += __shfl_xor(hitr, o, RR_WAVE);
+  // calculate_ndcg (eval.py:329-457): KL(softmax(targets) || softmax(scores)) with un-shifted f32 exponentials
+  // (:401-404: an overflowing exp gives inf / inf = NaN there and here), and NDCG over the first ceil(C * cut)
+  // positions of the TARGET order with rank-derived gains C + 1 - predicted rank (:406-425, cal_NDCG :309-325).
+  double se_t = 0, se_s = 0;
+  for (int i = lane; i < C; i += RR_WAVE) {
+    se_t += static_cast<double>(expf(t[i]));
+    se_s += static_cast<double>(expf(s[i]));
+  }
+  se_t = wave_sum_f64(se_t); se_s = wave_sum_f64(se_s);
+  int ncut = static_cast<int>(ceil(static_cast<double>(C) * ndcg_cut));
+  if (ncut > C) ncut = C;
+  double kl = 0, dcut = 0, icut = 0;
+  for (int i = lane; i < C; i += RR_WAVE) {
+    const double P = static_cast<double>(expf(t[i])) / se_t, Qd = static_cast<double>(expf(s[i])) / se_s;
+    kl += P * log(P / Qd);
+    if (i < ncut) {
+      // the reference ranks the predictions AFTER putting them in target order (:406-411), so a stable sort breaks
+      // tied predictions by target rank, not by list position
+      const int cand = to[i];
+      const float sc = s[cand];
+      int rank = 0;
+      for (int j = 0; j < C; ++j) rank += (s[j] > sc || (s[j] == sc && tr[j] < i)) ? 1 : 0;
+      const double disc = log2(static_cast<double>(i) + 2.0);
+      dcut += static_cast<double>(C - rank) / disc;
+      icut += static_cast<double>(C - i) / disc;
+    }
+  }
+  kl = wave_sum_f64(kl); dcut = wave_sum_f64(dcut); icut = wave_sum_f64(icut);
   if (lane == 0) {
+    st[8] = (pr[to[0]] < lenr) ? 1.0 : 0.0;
+    st[9] = dcut / icut;
+    st[10] = kl;
+    st[11] = static_cast<double>(hitr) / static_cast<double>(lenr);
     const double p0 = exp(static_cast<double>(t[po[0]])), t0 = exp(static_cast<double>(t[to[0]]));
     double p2 = p0, t2 = t0;                                  // NDCG2: nested lists -> no discount (:543)
     if (C > 1) { p2 += exp(static_cast<double>(t[po[1]])); t2 += exp(static_cast<double>(t[to[1]])); }
@@ -736,15 +789,17 @@ int rr_gauss_nll_bwd_f32(const float* mean, const float* var, int64_t stride, co
 }
 
 int rr_ranking_metrics_f32(const float* score, int64_t score_stride, const float* targets, const int32_t* seg_off,
-                           int Q, int max_len, int32_t* order, double* stats, rr_stream_t stream) {
+                           int Q, int max_len, double ratio, double ndcg_cut, int32_t* order, double* stats,
+                           rr_stream_t stream) {
   RR_CHECK_ARG(list_args_ok(score, targets, seg_off, Q, max_len) && order && stats && score_stride >= 1);
+  RR_CHECK_ARG(ratio >= 0.0 && ratio <= 1.0 && ndcg_cut >= 0.0 && ndcg_cut <= 1.0);
   if (max_len > kMaxLen) return RR_ERR_UNSUPPORTED;
   if (Q == 0) return RR_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = max_len > 0 ? max_len : 1;
-  const size_t lds = 4u * L * sizeof(float);
+  const size_t lds = 2u * L * sizeof(float) + 4u * L * sizeof(uint16_t);
   if (set_lds(ranking_metrics_kernel, lds) != RR_OK) return RR_ERR_LAUNCH;
-  ranking_metrics_kernel<<<Q, RR_WAVE, lds, s>>>(score, score_stride, targets, seg_off, L, order, stats);
+  ranking_metrics_kernel<<<Q, RR_WAVE, lds, s>>>(score, score_stride, targets, seg_off, L, ratio, ndcg_cut, order, stats);
   return rr_launch_status();
 }
 

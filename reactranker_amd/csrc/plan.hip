@@ -913,4 +913,44 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   return c.ar.overflow ? RR_ERR_WORKSPACE : c.status;
 }
 
+int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags, int which, int index,
+                          const float** ptr, int64_t* rows, int64_t* ld) {
+  int st = check(model, step);
+  if (st != RR_OK) return st;
+  RR_CHECK_ARG(step->workspace && ptr && rows && ld && index >= 0 && index < MAXD);
+  Ctx c;
+  c.launch = false; c.status = RR_OK; c.npq = 0;
+  c.ar.base = static_cast<char*>(step->workspace); c.ar.off = 0; c.ar.cap = step->workspace_bytes; c.ar.overflow = false;
+  c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
+  c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
+  c.split = (flags & RR_PLAN_F32_GEMM) == 0;
+  c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
+  c.s.main = c.s.side = c.s.aux = nullptr;
+  c.cur = nullptr;
+  Plan P;
+  memset(&P, 0, sizeof(P));
+  forward_all(c, *model, *step, P);                      // layout pass only
+  if (c.ar.overflow) return RR_ERR_WORKSPACE;
+  const int H = model->H;
+  const float* q = nullptr;
+  int64_t r = 0, l = H;
+  switch (which) {
+    case RR_SAVED_R_MSG: if (index < model->depth) { q = P.r.msgs[index]; r = step->r.nB; } break;
+    case RR_SAVED_R_H: q = P.r.h; r = step->r.nA; break;
+    case RR_SAVED_P_MSG: if (index < model->depth) { q = P.p.msgs[index]; r = step->p.nB; } break;
+    case RR_SAVED_P_H: q = P.p.h; r = step->p.nA; break;
+    case RR_SAVED_D_MSG: if (index < (model->diff_depth > 0 ? model->diff_depth : 1)) { q = P.d.msgs[index]; r = step->p.nA; } break;
+    case RR_SAVED_D_HID: q = P.d.hid; r = step->p.nA; break;
+    case RR_SAVED_VECS: q = P.d.vecs; r = step->p.M; l = P.d.ld_vecs; break;
+    case RR_SAVED_FFN_H: if (index >= 1 && index < model->n_ffn) { q = P.f.hs[index]; r = step->p.M; l = P.f.ld_hs[index]; } break;
+    case RR_SAVED_R_MSG0_U: if (step->mode == RR_STEP_PREFIX) { q = P.r.msg0_u; r = step->u.nB; } break;
+    case RR_SAVED_R_Z1_U: if (step->mode == RR_STEP_PREFIX) { q = P.r.z1_u; r = step->u.nB; } break;
+    default: return RR_ERR_ARG;
+  }
+  *ptr = q;
+  *rows = q ? r : 0;
+  *ld = l;
+  return RR_OK;
+}
+
 }  // extern "C"

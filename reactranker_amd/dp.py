@@ -9,7 +9,7 @@ local_count / global_count so the reduced gradient equals the single-process one
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+from typing import Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -126,3 +126,106 @@ def loss_weight(kind: str, local_queries: int, global_queries: int, local_cands:
     if kind == "ranknet":
         return (local_pairs or 0) / max(1, global_pairs or 1)
     raise ValueError(kind)
+
+
+# ------------------------------------------------------------------------------------------------ trainer-side glue
+def count_pairs(scope, targets) -> int:
+    """Ordered pairs (i, j), i != j, of one window with different targets inside the same query - `num_pairs = 2 *
+    num_pos_pairs` of the reference (train_pairwise.py:99-106: positive pairs `rel_diff > 0` and as many negative ones),
+    the normaliser of the RankNet loss (:147) - counted on the host from the targets the batch carries, so the trainer
+    never has to read the device-side count back.  64 distinct targets give 64 * 63 = 4032."""
+    import numpy as np
+    t = np.asarray(targets.detach().cpu() if torch.is_tensor(targets) else targets, dtype=np.float64).reshape(-1)
+    n, off = 0, 0
+    for c in scope:
+        q = t[off:off + c]
+        n += 2 * int((q[:, None] > q[None, :]).sum())
+        off += c
+    return n
+
+
+def step_counts(scope, targets) -> dict:
+    """The three normalisers a step can be averaged over: queries, candidates, ordered pairs."""
+    scope = [int(c) for c in scope]
+    return dict(queries=len(scope), cands=int(sum(scope)), pairs=count_pairs(scope, targets))
+
+
+def shard_query_batch(qb, rank: int, world: int):
+    """This rank's contiguous block of whole queries of one global step (a synth.QueryBatch or anything with the same
+    fields) + the counts of the WHOLE step, which weight the rank's gradient.  A rank can come out empty (fewer queries
+    than ranks): it still joins the step's all-reduce with a zero gradient."""
+    import copy
+    lo, hi = shard_queries(len(qb.scope), rank, world)
+    m0, m1 = int(sum(qb.scope[:lo])), int(sum(qb.scope[:hi]))
+    local = copy.copy(qb)
+    local.r_specs, local.p_specs = qb.r_specs[m0:m1], qb.p_specs[m0:m1]
+    local.scope, local.targets = list(qb.scope[lo:hi]), qb.targets[m0:m1]
+    local.add_features = None if qb.add_features is None else qb.add_features[m0:m1]
+    return local, step_counts(qb.scope, qb.targets)
+
+
+_KIND = {"mle": "mle", "evidential_ranking": "mle", "listnet": "listnet", "regression": "listnet", "gauss_regression": "listnet",
+         "mse": "listnet", "ranknet": "ranknet"}
+
+
+class Exchange:
+    """What a trainer needs from the process group, and nothing when there is none: the per-step gradient all-reduce
+    with the loss's weight, sums of validation statistics, and who writes checkpoints.  `group=None` with an initialised
+    torch.distributed means the default group; without torch.distributed every method is the identity, so the trainers
+    run ONE code path for 1 and N processes.
+
+    A batch handed to a data-parallel trainer is this rank's shard of a global step.  It carries `global` = the counts
+    of the whole step (dp.step_counts / dp.shard_query_batch) so that no collective is needed to weight the gradient;
+    without it the counts are all-reduced per step (one extra tiny collective and a host read)."""
+
+    def __init__(self, model: Optional[torch.nn.Module] = None, group=None):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.bucket = None
+        if self.on and model is not None:
+            self.bucket = GradBucket(model.parameters()).attach()
+
+    @property
+    def is_writer(self) -> bool:
+        return self.rank == 0
+
+    def close(self) -> None:
+        if self.bucket is not None:
+            self.bucket.detach()
+            self.bucket = None
+
+    def counts(self, batch, device) -> Tuple[dict, dict]:
+        """(local counts, global counts) of a step."""
+        local = step_counts(batch["scope"], batch["targets"]) if len(batch["scope"]) else dict(queries=0, cands=0, pairs=0)
+        if not self.on:
+            return local, local
+        g = batch.get("global")
+        if g is None:
+            v = torch.tensor([local["queries"], local["cands"], local["pairs"]], dtype=torch.float64, device=device)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            q, m, p = (int(x) for x in v.tolist())
+            g = dict(queries=q, cands=m, pairs=p)
+        return local, g
+
+    def weight(self, kind: str, local: dict, glob: dict) -> float:
+        return loss_weight(_KIND[kind], local["queries"], glob["queries"], local["cands"], glob["cands"],
+                           local["pairs"], glob["pairs"])
+
+    def reduce_grads(self, weight: float) -> None:
+        """p.grad <- sum over ranks of weight_r * p.grad_r, for every parameter of the model (missing gradients - an
+        empty shard, a window without ordered pairs - count as zeros)."""
+        if self.on:
+            self.bucket.allreduce(weight, group=self.group)
+
+    def sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.on:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def broadcast_model(self, model: torch.nn.Module) -> None:
+        """Identical replicas: rank 0's parameters and buffers everywhere (what DistributedDataParallel does at wrap time)."""
+        if self.on:
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)

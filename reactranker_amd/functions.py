@@ -933,6 +933,25 @@ class StepPlan:
     shape qualifies (H % 4 == 0) and no per-launch profiling is requested."""
     enabled = True
     _ws_bytes = {}
+    keep_last = False        # tests / embedding readers: remember the last step so saved() can look into its workspace
+    last = None
+
+    @staticmethod
+    def saved(which: int, index: int = 0) -> Optional[torch.Tensor]:
+        """A saved activation of the last plan step (rr_reaction_saved_f32; `which` = _lib.RR_SAVED_*) as a strided view
+        of its workspace - valid until the step's backward hands the workspace back.  Needs keep_last = True."""
+        if StepPlan.last is None:
+            raise RuntimeError("StepPlan.saved: no step on record (set StepPlan.keep_last = True before the forward)")
+        M, S, keep, ws, out, flags = StepPlan.last
+        p, rows, ld = C.c_void_p(), C.c_int64(), C.c_int64()
+        check(lib().rr_reaction_saved_f32(C.byref(M), C.byref(S), flags, which, index, C.byref(p), C.byref(rows), C.byref(ld)),
+              "rr_reaction_saved_f32")
+        if not p.value:
+            return None
+        off = p.value - ws.data_ptr()
+        width = M.H if which not in (_lib.RR_SAVED_VECS, _lib.RR_SAVED_FFN_H) else ld.value
+        flat = ws[off:off + rows.value * ld.value * 4].view(torch.float32)
+        return flat.view(rows.value, ld.value)[:, :width]
 
     @staticmethod
     def eligible(st, params) -> bool:
@@ -1029,6 +1048,8 @@ class ReactionModelFn(torch.autograd.Function):
             flags = StepPlan.flags()                    # the backward must lay the workspace out the same way
             check(lib().rr_reaction_forward(C.byref(M), C.byref(S), flags, stream()), "rr_reaction_forward")
             ctx.plan = (M, S, keep, ws, out, flags)
+            if StepPlan.keep_last:
+                StepPlan.last = ctx.plan
             if not any(ctx.needs_input_grad):          # (e.g. under torch.no_grad()) no backward will come for this step
                 _WorkspacePool.give(ws)
             ctx.st = st

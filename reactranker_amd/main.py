@@ -20,7 +20,7 @@ from typing import Callable, List, Optional, Sequence, Tuple, Union
 import torch
 
 from .base_model import build_model
-from .eval import ranking_metrics
+from .eval import calculate_ndcg, evaluate_top_scores
 from .run_train_pairwise import run_train
 from .train_listwise import train
 from .train_utils import build_lr_scheduler, build_optimizer
@@ -50,29 +50,56 @@ class Config:
                                                      ffn_last_layer="with_softplus"))
 
 
-def test(model, test_batches: Sequence, path_checkpoints: str, gpu: int, logger=None, target_name: Optional[str] = "ea"):
-    """Reference train/test_listwise.py:10-86: load the fold's checkpoint, flip the sign of raw targets unless 'lgk'
-    (:30-35), evaluate -> (average_score [top-1], average_pred_in_targ [top-25% recall], average_top1_in_pred)."""
+def test(model, test_batches: Sequence, path_checkpoints: str, gpu: int, logger=None, target_name: Optional[str] = "ea",
+         cal_ngcd: bool = False, is_order: bool = True, return_order: bool = True, task_type: Optional[str] = None,
+         exchange=None):
+    """Reference train/test_listwise.py:10-86 (and test_ranknet.py:30-80, which reports the same triple): load the
+    fold's checkpoint, flip the sign of raw targets unless 'lgk' (:30-35), evaluate with `evaluate_top_scores` at
+    ratio 0.25 (:51-54) -> (average_score [top-1], average_pred_in_targ [predicted top-25 % inside the target top-25 %],
+    average_top1_in_pred [the target's top-1 inside the predicted top-25 %]).  With cal_ngcd also `calculate_ndcg` at
+    NDCG_cut = 0.25 on the de-standardised outputs (:58-63), logged, and - with return_order - its per-candidate
+    listing appended to the return value (:83-84; the SMILES column stays with the DataFrame side: None).
+    task_type 'MC_dropout' keeps the model in train mode (:42-45).  exchange: a reactranker_amd.dp.Exchange when every
+    rank evaluates its own shard of the test queries (the means are then over all ranks' queries)."""
     scaler = load_checkpoint(path_checkpoints, model, map_location="cpu")
-    model = model.cuda(gpu).eval()
+    model = model.cuda(gpu)
+    model.train() if task_type == "MC_dropout" else model.eval()
     sign = 1.0
-    if scaler is not None and scaler.get("means") is not None and target_name is not None and target_name != "lgk":
-        sign = -1.0
+    means = stds = None
+    if scaler is not None and scaler.get("means") is not None:
+        means, stds = scaler["means"], scaler["stds"]
+        if target_name is not None and target_name != "lgk":
+            sign = -1.0
+    batches = [(b["r"], b["p"], b["scope"], sign * torch.as_tensor(b["targets"], dtype=torch.float32), b.get("add"))
+               for b in test_batches]
     with torch.no_grad():
-        top1, recall25, top25, _ = ranking_metrics(
-            model, gpu, [(b["r"], b["p"], b["scope"], sign * torch.as_tensor(b["targets"], dtype=torch.float32), b.get("add"))
-                         for b in test_batches])
+        top1, recall25, top25 = evaluate_top_scores(model, gpu, batches, ratio=0.25, exchange=exchange)
+        if cal_ngcd:
+            ndcg, kl_div, order, smiles_and_index = calculate_ndcg(model, gpu, batches, NDCG_cut=0.25,
+                                                                   is_order=is_order, means=means, stds=stds, exchange=exchange)
     if logger is not None:
+        if cal_ngcd:
+            logger.info("test: NDCG0.25 {}, KL divergence {}".format(ndcg, kl_div))
         logger.info("test: average score {:.4f}, pred top25% in targ top25% {:.4f}, targ top1 in pred top25% {:.4f}"
                     .format(top1, recall25, top25))
+    if cal_ngcd and return_order:
+        return float(top1), float(recall25), float(top25), order, smiles_and_index
     return float(top1), float(recall25), float(top25)
 
 
-def run(cfg: Config, folds: Callable[[int], Tuple[Sequence, Sequence, Sequence]], logger=None) -> List[List[float]]:
-    """Returns the per-fold test scores [[top1, pred_top25_in_targ_top25, top1_in_pred_top25], ...] (main.py:173)."""
+def run(cfg: Config, folds: Callable[[int], Tuple[Sequence, Sequence, Sequence]], logger=None, group=None) -> List[List[float]]:
+    """Returns the per-fold test scores [[top1, pred_top25_in_targ_top25, top1_in_pred_top25], ...] (main.py:173).
+    Under an initialised torch.distributed (`group`: a process group, None = the default one) `folds(i)` supplies THIS
+    rank's shards of fold i (reactranker_amd.dp.shard_query_batch); training, validation and the test evaluation are
+    data-parallel (see train_listwise.train), rank 0 writes checkpoints and logs, every rank returns the same scores."""
+    from .dp import Exchange
+    ex = Exchange(None, group)
     os.makedirs(cfg.path, exist_ok=True)
     if logger is None:
         logger = logging.getLogger("reactranker_amd.main")
+    if not ex.is_writer:
+        logger = logging.getLogger("reactranker_amd.main.silent")
+        logger.disabled = True
     paths = cfg.path
     if cfg.save_metric == "all":                                 # main.py:68-74
         paths = [os.path.join(cfg.path, m) for m in ("T1", "T25_in_T25", "T25")]
@@ -94,19 +121,24 @@ def run(cfg: Config, folds: Callable[[int], Tuple[Sequence, Sequence, Sequence]]
             mk.update(task_num=2, task_type="evidential_ranking")
         model = build_model(add_features_dim=cfg.add_features_dim, **mk).cuda(cfg.gpu)
         optimizer = build_optimizer(model)
-        n_train = sum(len(b["scope"]) for b in train_b)
+        # queries of the WHOLE training set (a data-parallel batch is a shard and carries its step's global counts): every
+        # rank must build the same learning-rate schedule
+        n_train = sum((b.get("global") or {}).get("queries", len(b["scope"])) for b in train_b)
         scheduler = build_lr_scheduler(optimizer, warmup_epochs=cfg.warmup_epochs, total_epochs=cfg.total_epochs,
                                        train_data_size=max(n_train, cfg.batch_size), batch_size=cfg.batch_size,
                                        init_lr=cfg.init_lr, max_lr=cfg.max_lr, final_lr=cfg.final_lr)
         if cfg.task_type == "ranknet":
             run_train(model, scheduler, train_b, val_b, ck, optimizer, cfg.total_epochs, seed, cfg.gpu,
                       train_strategy=cfg.train_strategy, task_type="baseline", logger=logger,
-                      target_name=cfg.target_name, save_metric=cfg.save_metric)
+                      target_name=cfg.target_name, save_metric=cfg.save_metric, group=group)
         else:
             train(model, scheduler, train_b, val_b, ck, optimizer, cfg.total_epochs, seed, cfg.gpu,
                   task_type=cfg.task_type, logger=logger, save_metric=cfg.save_metric, target_name=cfg.target_name,
-                  normalize_target=cfg.normalize_target)
+                  normalize_target=cfg.normalize_target, group=group)
+        if ex.on:                                                # rank 0's checkpoint must be on disk before anyone loads it
+            import torch.distributed as dist
+            dist.barrier(group=group)
         test_path = ck[0] if cfg.save_metric == "all" else ck    # main.py:164-168
-        test_score.append(list(test(model, test_b, test_path, cfg.gpu, logger, cfg.target_name)))
+        test_score.append(list(test(model, test_b, test_path, cfg.gpu, logger, cfg.target_name, exchange=ex))[:3])
     logger.info("test score for k_fold vailidation is: {}".format(test_score))
     return test_score

@@ -53,13 +53,26 @@ def standardize_targets(train_targets, val_targets, target_name: str = "ea", nor
     return f(tr), val_std, mean, std
 
 
-def standardize_batches(train_batches, val_batches, target_name="ea", normalize_target=True, save_metric=None):
+def standardize_batches(train_batches, val_batches, target_name="ea", normalize_target=True, save_metric=None, exchange=None):
     """standardize_targets over lists of packed batches: statistics from ALL training targets (the reference computes
-    them on the training DataFrame), new batch dicts with standardised float32 `targets`."""
+    them on the training DataFrame), new batch dicts with standardised float32 `targets`.  With a data-parallel
+    `exchange` the statistics are those of every rank's training targets (gathered in rank order), so each rank applies
+    the transformation the single-process run applies."""
     def cat(bs):
         return np.concatenate([np.asarray(torch.as_tensor(b["targets"]).cpu(), np.float64).reshape(-1) for b in bs]) \
             if len(bs) else np.zeros(0)
-    tr, va, mean, std = standardize_targets(cat(train_batches), cat(val_batches), target_name, normalize_target, save_metric)
+    tr_local, va_local = cat(train_batches), cat(val_batches)
+    if exchange is not None and exchange.on:
+        import torch.distributed as dist
+        parts = [None] * exchange.world
+        dist.all_gather_object(parts, tr_local, group=exchange.group)
+        tr_all, _, mean, std = standardize_targets(np.concatenate(parts), np.zeros(0), target_name, normalize_target, save_metric)
+        lo = sum(len(q) for q in parts[:exchange.rank])
+        tr = tr_all[lo:lo + len(tr_local)]
+        # the validation transform uses the training statistics only: apply it to this rank's validation targets
+        _, va, _, _ = standardize_targets(np.concatenate(parts), va_local, target_name, normalize_target, save_metric)
+    else:
+        tr, va, mean, std = standardize_targets(tr_local, va_local, target_name, normalize_target, save_metric)
 
     def split(bs, flat):
         out, off = [], 0
@@ -101,21 +114,42 @@ def train(model: torch.nn.Module, scheduler, train_batches: Union[Sequence, Call
           val_batches: Sequence, path_checkpoints: Union[str, List[str], None], optimizer, epochs: int, seed: int, gpu: int,
           task_type: str = "mle", logger=None, save_metric: Optional[str] = None, max_coeff: float = 1e-4,
           mean: float = 0.0, std: float = 1.0, target_name: Optional[str] = None, normalize_target=True,
-          epoch_hook: Optional[Callable] = None):
+          epoch_hook: Optional[Callable] = None, group=None):
     """Same control flow as the reference train(): fixed seed, per batch forward / loss / zero_grad / backward /
     optimizer.step / scheduler.step (train_listwise.py:287-290), validation with ranking_metrics after every epoch,
     checkpoint whenever the selected metric does not get worse (:310-350).  `train_batches` is a sequence, or a
     callable epoch -> iterable (the reference reshuffles with seed=epoch, :178).  Returns the per-epoch history.
     epoch_hook(epoch, model, record): optional observer called after every epoch's validation (not in the reference; the
-    trajectory tests read the validation scores through it)."""
+    trajectory tests read the validation scores through it).
+
+    Data parallel (the reference has no distributed code): under an initialised torch.distributed
+    (`group` = a process group, None = the default one) every rank passes ITS shard of every global step - whole queries,
+    see reactranker_amd.dp.shard_query_batch - and of the validation queries.  Per step the rank's gradient is weighted
+    by its share of the loss's normaliser and summed over the ranks in one all-reduce of the flat bucket the explicit
+    backward writes into; validation statistics are summed over the ranks; rank 0 writes the checkpoints; every rank
+    returns the same history.  One process (no torch.distributed) runs the same code with the exchange switched off."""
+    from .dp import Exchange
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
+    model = model.cuda(gpu)
+    ex = Exchange(model, group)
+    if ex.on and task_type not in ("mle", "listnet", "evidential_ranking", "regression", "gauss_regression"):
+        raise ValueError(f"data-parallel training covers losses with ONE normaliser; {task_type!r} sums two")
+    try:
+        return _train(model, scheduler, train_batches, val_batches, path_checkpoints, optimizer, epochs, gpu, task_type, logger,
+                      save_metric, max_coeff, mean, std, target_name, normalize_target, epoch_hook, ex)
+    finally:
+        ex.close()
+
+
+def _train(model, scheduler, train_batches, val_batches, path_checkpoints, optimizer, epochs, gpu, task_type, logger, save_metric,
+           max_coeff, mean, std, target_name, normalize_target, epoch_hook, ex):
     if target_name is not None:                       # raw targets: standardise / flip like the reference (:66-122)
         if callable(train_batches):
             raise ValueError("target standardisation needs the training batches as a sequence (statistics over all of them)")
         train_batches, val_batches, mean, std = standardize_batches(list(train_batches), list(val_batches), target_name,
-                                                                     normalize_target, save_metric)
-    model = model.cuda(gpu)
+                                                                     normalize_target, save_metric, ex)
+    ex.broadcast_model(model)                         # identical replicas (a no-op for one process)
     # dropout streams: every forward draws a fresh stream seed from torch's generator (mpn._fresh_seed), which the
     # manual_seed above makes reproducible - like the reference, whose nn.Dropout advances that generator per call.
     # model.dropout_seed (a test knob that pins ONE stream for every step) must stay unset here.
@@ -123,28 +157,37 @@ def train(model: torch.nn.Module, scheduler, train_batches: Union[Sequence, Call
         model.dropout_seed = None
     score_old = [0.0, 0.0, 0.0] if save_metric == "all" else 0.0
     history = []
-    say = logger.info if logger is not None else (lambda *_: None)
+    say = logger.info if (logger is not None and ex.is_writer) else (lambda *_: None)
+    dev = next(model.parameters()).device
     for epoch in range(epochs):
         say("learning rate is: {}".format(optimizer.param_groups[0]["lr"]))
         model.train()
-        loss = torch.zeros(1)
+        loss = torch.zeros(1, device=dev)
         for b in (train_batches(epoch) if callable(train_batches) else train_batches):
-            output = model(b["r"], b["p"], gpu=gpu, add_features=b.get("add"))
-            loss = batch_loss(task_type, output, b["scope"], b["targets"], gpu, epoch, epochs, max_coeff)
             optimizer.zero_grad()
-            loss.sum().backward()
+            if len(b["scope"]) > 0:
+                output = model(b["r"], b["p"], gpu=gpu, add_features=b.get("add"))
+                loss = batch_loss(task_type, output, b["scope"], b["targets"], gpu, epoch, epochs, max_coeff)
+                loss.sum().backward()
+            else:                                       # an empty shard: this rank adds nothing to the step
+                loss = torch.zeros(1, device=dev)
+            if ex.on:
+                local, glob = ex.counts(b, dev)
+                w = ex.weight(task_type, local, glob)
+                ex.reduce_grads(w)
+                loss = loss.detach().reshape(-1)[:1] * w    # summed over the ranks below: the whole step's loss
             optimizer.step()
             scheduler.step()
         model.eval()
         top1, recall25, top25, ndcg = ranking_metrics(
-            model, gpu, [(b["r"], b["p"], b["scope"], b["targets"], b.get("add")) for b in val_batches])
+            model, gpu, [(b["r"], b["p"], b["scope"], b["targets"], b.get("add")) for b in val_batches], exchange=ex)
         saved = False
 
         def keep(path):
             nonlocal saved
-            if path is not None:
+            saved = True
+            if path is not None and ex.is_writer:
                 save_checkpoint(path, model, mean, std)
-                saved = True
         if save_metric is None or save_metric == "average_score":
             if top1 >= score_old:
                 score_old = top1
@@ -169,7 +212,9 @@ def train(model: torch.nn.Module, scheduler, train_batches: Union[Sequence, Call
                 keep(path_checkpoints)
         else:
             raise Exception("Unknown save metric")
-        rec = dict(epoch=epoch + 1, train_loss=float(loss.detach().sum()), top1=float(top1), top1_in_pred_top25=float(top25),
+        saved = saved and path_checkpoints is not None
+        last_loss = float(ex.sum(loss.detach().sum().reshape(1).clone()))     # the reference logs the last step's loss (:353)
+        rec = dict(epoch=epoch + 1, train_loss=last_loss, top1=float(top1), top1_in_pred_top25=float(top25),
                    pred_top25_in_targ_top25=float(recall25), ndcg=[float(x) for x in ndcg], checkpoint=saved)
         history.append(rec)
         if epoch_hook is not None:

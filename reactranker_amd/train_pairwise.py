@@ -10,36 +10,57 @@ from __future__ import annotations
 
 from typing import Iterable
 
-import numpy as np
 import torch
 
 from .loss import ranknet_lambda, ranknet_loss
 
 
 def factorized_training_loop(epoch: int, model, optimizer, scheduler, batches: Iterable, sigma: float = 1.0,
-                             training_algo: str = "sum_session", gpu: int = 0) -> float:
+                             training_algo: str = "sum_session", gpu: int = 0, exchange=None) -> float:
     """One epoch; returns the mean of the per-step losses like the reference (:173).
     training_algo: 'sum_session' (autograd through the pair losses, :117-122,147-148) or 'accelerate_grad'
-    (closed-form lambdas pushed through y_pred.backward, :123-137,149-151)."""
+    (closed-form lambdas pushed through y_pred.backward, :123-137,149-151).
+
+    The window's ordered-pair count - the loss's normaliser (:106,147) and the reason a window is skipped (:101-103) - is
+    counted on the host from the targets the batch carries (dp.count_pairs, cached on the batch), and the per-step losses
+    stay on the device until the epoch ends: no host synchronisation per step (the reference reads `.item()` per query).
+    exchange: a reactranker_amd.dp.Exchange; a batch is then this rank's shard of the window and the normaliser is the
+    whole window's pair count."""
+    from .dp import Exchange, step_counts
     if training_algo not in ("sum_session", "accelerate_grad"):
         raise ValueError("training algo {} not implemented".format(training_algo))
+    ex = exchange if exchange is not None else Exchange()
+    dev = next(model.parameters()).device
     minibatch_loss = []
     for b in batches:
-        y_pred = model(b["r"], b["p"], gpu=gpu, add_features=b.get("add"))
-        if y_pred.dim() > 1:
-            y_pred = y_pred[:, 0]
-        loss_sum, pairs = ranknet_loss(y_pred if training_algo == "sum_session" else y_pred.detach(), b["scope"],
-                                       b["targets"], sigma, gpu)
-        if int(pairs) == 0:                              # windows without any ordered pair carry no information (:101-103)
+        if "_counts" not in b:
+            b["_counts"] = step_counts(b["scope"], b["targets"]) if len(b["scope"]) else dict(queries=0, cands=0, pairs=0)
+        local = b["_counts"]
+        glob = ex.counts(b, dev)[1] if ex.on else local
+        pairs = glob["pairs"]
+        if pairs == 0:                                   # windows without any ordered pair carry no information (:101-103)
             continue
-        loss = loss_sum / pairs
-        minibatch_loss.append(float(loss.detach().sum()))
-        if training_algo == "sum_session":
-            loss.sum().backward()
-        else:
-            back = ranknet_lambda(y_pred, b["scope"], b["targets"], sigma, gpu)
-            y_pred.backward(back / pairs)
-        optimizer.step()
         model.zero_grad()
+        if local["pairs"] > 0:
+            y_pred = model(b["r"], b["p"], gpu=gpu, add_features=b.get("add"))
+            if y_pred.dim() > 1:
+                y_pred = y_pred[:, 0]
+            loss_sum, _ = ranknet_loss(y_pred if training_algo == "sum_session" else y_pred.detach(), b["scope"],
+                                       b["targets"], sigma, gpu)
+            loss = loss_sum / pairs
+            if training_algo == "sum_session":
+                loss.sum().backward()
+            else:
+                back = ranknet_lambda(y_pred, b["scope"], b["targets"], sigma, gpu)
+                y_pred.backward(back / pairs)
+            minibatch_loss.append(loss.detach().sum().reshape(1))
+        else:                                            # this rank's shard has no ordered pair: zero gradient, zero loss
+            minibatch_loss.append(torch.zeros(1, device=dev))
+        ex.reduce_grads(1.0)                             # already normalised by the WINDOW's pair count: a plain sum
+        optimizer.step()
         scheduler.step()
-    return float(np.mean(minibatch_loss)) if minibatch_loss else float("nan")
+    model.zero_grad()
+    if not minibatch_loss:
+        return float("nan")
+    per_step = ex.sum(torch.cat(minibatch_loss).double())
+    return float(per_step.mean())

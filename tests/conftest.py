@@ -17,3 +17,50 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---------------------------------------------------------------------------------------------- measured parity errors
+# Every `-m gpu` parity test reports what it MEASURED (not just that it stayed under its bound) through the `parity_log`
+# fixture; the lines are merged into gpurun_out/parity_errors.txt (one block per test id, the latest run wins) and the
+# builder copies that file to profiles/rNN_parity_errors.txt.  $RR_PARITY_LOG overrides the path.
+_PARITY = {}
+
+
+def _parity_path():
+    return os.environ.get("RR_PARITY_LOG", os.path.join(REPO, "gpurun_out", "parity_errors.txt"))
+
+
+@pytest.fixture
+def parity_log(request):
+    lines = _PARITY.setdefault(request.node.nodeid, [])
+    del lines[:]
+
+    def log(msg):
+        lines.append(str(msg))
+        print("[parity] " + str(msg))
+    return log
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    path = _parity_path()
+    merged = {}
+    if os.path.exists(path):
+        cur = None
+        with open(path) as f:
+            for ln in f:
+                ln = ln.rstrip("\n")
+                if ln.startswith("## "):
+                    cur = ln[3:]
+                    merged[cur] = []
+                elif cur is not None and ln.startswith("   "):
+                    merged[cur].append(ln[3:])
+    merged.update({k: v for k, v in _PARITY.items() if v})
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write("# measured errors of the -m gpu parity tests (tests/conftest.py: parity_log); latest run per test id\n")
+        for k in sorted(merged):
+            f.write("## " + k + "\n")
+            for ln in merged[k]:
+                f.write("   " + ln + "\n")

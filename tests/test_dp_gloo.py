@@ -150,3 +150,76 @@ def test_attached_bucket_with_a_gradient_from_outside_the_explicit_backward():
     ret = mgr.dict()
     mp.spawn(_mixed_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------- trainer-side glue
+def test_count_pairs_is_the_ranknet_normaliser():
+    from reactranker_amd.dp import count_pairs, step_counts
+    rng = np.random.default_rng(3)
+    scope = [1, 2, 7, 5]
+    t = np.round(rng.standard_normal(sum(scope)), 1).astype(np.float32)       # rounded: ties do not count
+    s = torch.tensor(rng.standard_normal(sum(scope)).astype(np.float32))
+    _, pairs = O.ranknet_sum_session(s, scope, torch.tensor(t), 1.0)          # train_pairwise.py:99-106
+    assert count_pairs(scope, t) == int(pairs) == count_pairs(scope, torch.tensor(t))
+    assert step_counts(scope, t) == dict(queries=4, cands=15, pairs=int(pairs))
+
+
+def test_shard_query_batch_partitions_whole_queries_and_keeps_the_global_counts():
+    from reactranker_amd.dp import shard_query_batch, step_counts
+    qb = synth.make_queries(5, len(SCOPE), SCOPE, atoms_lo=4, atoms_hi=8)
+    for world in (1, 2, 3, 8):
+        parts = [shard_query_batch(qb, r, world) for r in range(world)]
+        assert all(g == step_counts(qb.scope, qb.targets) for _, g in parts)
+        assert sum((p.scope for p, _ in parts), []) == list(qb.scope)
+        assert np.array_equal(np.concatenate([p.targets for p, _ in parts]), qb.targets)
+        assert sum(len(p.p_specs) for p, _ in parts) == len(qb.p_specs)
+        for p, _ in parts:
+            assert len(p.r_specs) == len(p.p_specs) == sum(p.scope) == len(p.add_features)
+    assert [len(p.scope) for p, _ in [shard_query_batch(qb, r, 8) for r in range(8)]].count(0) == 3      # empty shards exist
+
+
+def _exchange_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from reactranker_amd.dp import Exchange, shard_query_batch
+        from reactranker_amd.eval import _mean_stats
+        ex = Exchange(None)
+        assert ex.on and ex.world == world and ex.rank == rank and ex.is_writer == (rank == 0)
+        rng = np.random.default_rng(1)
+        stats = torch.tensor(rng.standard_normal((7, 12)))                    # 7 queries, ragged over the ranks: 4 + 3
+        lo, hi = shard_queries(7, rank, world)
+        m = _mean_stats(stats[lo:hi], ex)
+        ok = np.allclose(m, stats.mean(dim=0).numpy(), rtol=0, atol=1e-14)
+        qb = synth.make_queries(5, len(SCOPE), SCOPE, atoms_lo=4, atoms_hi=8)
+        mine, glob = shard_query_batch(qb, rank, world)
+        b = dict(scope=mine.scope, targets=mine.targets)                      # no `global`: the counts are all-reduced
+        local, g2 = ex.counts(b, "cpu")
+        ok = ok and g2 == glob and local["queries"] == len(mine.scope)
+        w = [ex.weight(k, local, g2) for k in ("mle", "listnet", "ranknet", "evidential_ranking", "regression")]
+        tot = ex.sum(torch.tensor(w, dtype=torch.float64))
+        ok = ok and bool(torch.allclose(tot, torch.ones(5, dtype=torch.float64), atol=1e-12))     # the weights partition 1
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_sums_validation_statistics_and_partitions_the_loss_weights():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_exchange_without_a_process_group_is_the_identity():
+    from reactranker_amd.dp import Exchange
+    ex = Exchange(None)
+    assert not ex.on and ex.world == 1 and ex.is_writer
+    t = torch.arange(3.0)
+    assert ex.sum(t) is t
+    local, glob = ex.counts(dict(scope=[2, 3], targets=np.array([1., 2., 3., 1., 2.])), "cpu")
+    assert local == glob == dict(queries=2, cands=5, pairs=2 * (1 + 3))
+    ex.reduce_grads(0.5)
+    ex.close()

@@ -1,0 +1,77 @@
+"""SURVEY.md section 8e through the TRAINERS (round-3 review: data-parallel training existed only inside bench.py):
+`reactranker_amd.main.run` -> `train_listwise.train` / `run_train_pairwise.run_train` under torch.distributed.  A fresh
+2-process job (tests/dp_trainer_job.py under `python -m torch.distributed.run`, every rank holding a RAGGED shard of every
+global step) must reproduce the 1-process job's per-epoch training loss, validation metrics, checkpoint decisions and test
+scores, for ListMLE, ListNet, RankNet (sum_session) and evidential_ranking.  On a one-GPU box the two ranks share GPU 0
+(RR_SINGLE_DEVICE=1) and talk over gloo; with RR_DIST_BACKEND=nccl and two GPUs the same file runs over RCCL unchanged."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JOB = os.path.join(REPO, "tests", "dp_trainer_job.py")
+KINDS = ["mle", "listnet", "ranknet", "evidential_ranking"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def jobs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("dp_trainers")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = str(d / "one.json")
+    subprocess.run([sys.executable, JOB, "--out", one, "--ckdir", str(d / "ck1")], check=True, env=env, timeout=900)
+    two_gpus = torch.cuda.device_count() >= 2
+    env2 = dict(env)
+    if not two_gpus:
+        env2.update(RR_SINGLE_DEVICE="1", RR_DIST_BACKEND="gloo")
+    else:
+        env2.setdefault("RR_DIST_BACKEND", "nccl")
+    two = str(d / "two.json")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                    "127.0.0.1", "--master-port", str(_free_port()), JOB, "--out", two, "--ckdir", str(d / "ck2")],
+                   check=True, env=env2, timeout=900)
+    with open(one) as f:
+        a = json.load(f)
+    with open(two) as f:
+        b = json.load(f)
+    assert a["world"] == 1 and b["world"] == 2
+    return a["result"], b["result"], b["backend"], str(d)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_two_process_trainer_reproduces_the_one_process_trainer(jobs, kind, parity_log):
+    one, two, backend, d = jobs
+    h1, h2 = one[kind]["history"], two[kind]["history"]
+    assert len(h1) == len(h2) == 3
+    worst_loss = worst_metric = 0.0
+    for e1, e2 in zip(h1, h2):
+        rel = abs(e1["train_loss"] - e2["train_loss"]) / max(1e-6, abs(e1["train_loss"]))
+        worst_loss = max(worst_loss, rel)
+        for k in ("top1", "top1_in_pred_top25", "pred_top25_in_targ_top25"):
+            worst_metric = max(worst_metric, abs(e1[k] - e2[k]))
+        if "ndcg" in e1:
+            worst_metric = max(worst_metric, max(abs(x - y) for x, y in zip(e1["ndcg"], e2["ndcg"])))
+        assert e1["checkpoint"] == e2["checkpoint"] and e1.get("checkpoint_all") == e2.get("checkpoint_all")
+    parity_log(f"{kind} backend={backend}: max rel |loss_2proc - loss_1proc| {worst_loss:.2e}, max |metric diff| {worst_metric:.2e}")
+    assert worst_loss <= 1e-5 and worst_metric <= 1e-5, (kind, worst_loss, worst_metric)
+    assert h1[-1]["train_loss"] < h1[0]["train_loss"]                         # the epochs trained
+    t1, t2 = one[kind]["test"], two[kind]["test"]
+    assert max(abs(x - y) for x, y in zip(t1[0], t2[0])) <= 1e-5
+    # rank 0 - and only rank 0 - wrote the three 'all' checkpoints (main.py:68-74 layout)
+    for sub in ("T1", "T25_in_T25", "T25"):
+        assert os.path.exists(os.path.join(d, "ck2", kind, sub, "0.pt"))

@@ -173,3 +173,81 @@ def test_ranking_metrics_kernel_against_reference_loop(golden_dir):
     assert (top1, top25) == (r_top1, r_top25) and abs(rec - r_rec) < 1e-12 and np.allclose(nd, r_nd, rtol=0, atol=1e-12)
     _, order = RE.ranking_stats(torch.tensor(np.concatenate(sc)).cuda(), scope, torch.tensor(np.concatenate(tg)), 0)
     assert np.array_equal(order.cpu().numpy(), np.concatenate(r_orders).astype(np.int32))
+
+
+@pytest.mark.parametrize("name", ("plain", "pred_ties", "ties", "two_col", "scaled", "two_col_scaled"))
+def test_top_scores_and_calculate_ndcg_kernel_against_reference_loops(golden_dir, name):
+    """rr_ranking_metrics_f32's evaluate_top_scores / calculate_ndcg statistics vs the numbers the reference's own
+    evaluate_top_scores (eval.py:76-177) and calculate_ndcg (:329-457) produced on preset scores
+    (tests/golden/top_scores.npz), through the trainer-level mirrors that take a model and batches."""
+    from reactranker_amd import eval as RE
+    from tests.test_oracle_golden import top_scores_case
+    sc, tg, scope, scaler, E = top_scores_case(golden_dir, name)
+    scores = torch.tensor(np.concatenate(sc)).cuda()
+    targets = np.concatenate(tg)
+
+    class _Model:                                       # two batches of whole queries with preset outputs
+        training = False
+
+        def __init__(self):
+            self.at = 0
+
+        def __call__(self, r, p, gpu=None, add_features=None):
+            out = scores[self.at:self.at + r]
+            self.at += r
+            return out
+    half = len(scope) // 2
+    n0 = int(sum(scope[:half]))
+
+    def batches():
+        return [(n0, None, scope[:half], targets[:n0], None),
+                (int(sum(scope[half:])), None, scope[half:], targets[n0:], None)]
+    for ratio in (0.25, 0.1, 0.5):
+        got = RE.evaluate_top_scores(_Model(), 0, batches(), ratio=ratio)
+        want = E[f"{name}.top_scores_r{ratio}"]
+        assert got[0] == want[0] and abs(got[1] - want[1]) < 1e-12 and got[2] == want[2], (name, ratio, got, want)
+        one = RE.top_scores_from_scores(scores, scope, targets, 0, ratio)
+        assert one[0] == want[0] and abs(one[1] - want[1]) < 1e-12 and one[2] == want[2]
+    means, stds = scaler if scaler is not None else (None, None)
+    first = [s[:, 0] if s.ndim > 1 else s for s in sc]
+    for cut in (0.5, 0.25):
+        nd, kl, rows, _ = RE.calculate_ndcg(_Model(), 0, batches(), NDCG_cut=cut, means=means, stds=stds)
+        o_nd, o_kl, _ = O.calculate_ndcg_from_scores(first, tg, cut, means, stds)
+        assert abs(nd - o_nd) < 1e-6 and abs(kl - o_kl) < 1e-6 * max(1.0, abs(o_kl)), (name, cut)   # f64 vs torch f32
+        assert abs(kl - float(E[f"{name}.kl"])) < 1e-6 * max(1.0, abs(kl))
+        if "ties" not in name:          # with ties the reference's unstable torch.sort decides (see the oracle's test)
+            assert abs(nd - float(E[f"{name}.ndcg_c{cut}"])) < 1e-6, (name, cut)
+            want_rows = E[f"{name}.order_rows"]
+            assert np.allclose(np.asarray(rows), want_rows, rtol=0, atol=2e-6)      # the per-candidate listing
+    raw, _, rows, _ = RE.calculate_ndcg(_Model(), 0, batches(), is_order=False)
+    assert raw is None and len(rows) == len(targets)
+
+
+def test_top_scores_third_value_is_not_ranking_metrics_third_value():
+    """The two 'top-25 %' hits differ in kind: ranking_metrics asks for the PREDICTED top-1 inside the target top-25 %
+    (eval.py:526-530), evaluate_top_scores for the TARGET's top-1 inside the predicted top-25 % (:156-159)."""
+    from reactranker_amd import eval as RE
+    s = torch.tensor([9., 8., 7., 6., 5., 4., 3., 2.]).cuda()          # predicted order 0, 1, 2, ...
+    t = torch.tensor([6., 1., 2., 3., 4., 5., 8., 7.])                 # target order 6, 7, 0, ... ; cut = 2
+    _, _, top25, _ = RE.ranking_metrics_from_scores(s, [8], t, 0)
+    a, b, c = RE.top_scores_from_scores(s, [8], t, 0)
+    assert top25 == 0.0 and c == 0.0 and a == 0.0 and b == 0.0
+    t2 = torch.tensor([7., 8., 2., 3., 4., 5., 1., 0.])                # target order 1, 0: predicted top-1 IS in it ...
+    assert RE.ranking_metrics_from_scores(s, [8], t2, 0)[2] == 1.0
+    assert RE.top_scores_from_scores(s, [8], t2, 0)[2] == 1.0          # ... and target top-1 (1) is in predicted {0, 1}
+    t3 = torch.tensor([7., 1., 8., 3., 4., 5., 6., 0.])                # target order 2, 0: predicted top-1 (0) is in it,
+    assert RE.ranking_metrics_from_scores(s, [8], t3, 0)[2] == 1.0     # but the target's top-1 (2) is predicted third
+    assert RE.top_scores_from_scores(s, [8], t3, 0)[2] == 0.0
+    rng = np.random.default_rng(11)
+    scope = [1, 2, 64, 65, 130, 7, 300]
+    sc = [np.round(rng.standard_normal(c), 1).astype(np.float32) for c in scope]
+    tg = [rng.standard_normal(c).astype(np.float32) for c in scope]
+    for ratio in (0.25, 0.03, 1.0):
+        want = O.top_scores_from_scores(sc, tg, ratio)
+        got = RE.top_scores_from_scores(torch.tensor(np.concatenate(sc)).cuda(), scope, np.concatenate(tg), 0, ratio)
+        assert got[0] == want[0] and abs(got[1] - want[1]) < 1e-12 and got[2] == want[2]
+    for cut in (0.5, 1.0, 0.01):
+        want = O.calculate_ndcg_from_scores(sc, tg, cut)
+        stats, _ = RE.ranking_stats(torch.tensor(np.concatenate(sc)).cuda(), scope, np.concatenate(tg), 0, 0.25, cut)
+        assert np.allclose(stats[:, 9].cpu().numpy(), want[2][:, 0], rtol=0, atol=1e-6)
+        assert np.allclose(stats[:, 10].cpu().numpy(), want[2][:, 1], rtol=1e-6, atol=1e-6)

@@ -198,3 +198,36 @@ def test_ranking_metrics_against_reference_loop(golden_dir):
         assert abs(rec - float(E[name + ".recall25"])) < 1e-15
         assert np.allclose(nd, E[name + ".ndcg"], rtol=0, atol=1e-14)
         assert np.array_equal(np.concatenate(orders).astype(np.int32), E[name + ".order"])
+
+
+TOP_SCORES_CASES = ("plain", "pred_ties", "ties", "two_col", "scaled", "two_col_scaled")
+
+
+def top_scores_case(golden_dir, name):
+    """(per-query score rows, per-query targets, scope, scaler or None, npz) of one tests/golden/top_scores.npz case."""
+    E = np.load(golden_dir + "/top_scores.npz")
+    scope = E[name + ".scope"].tolist()
+    offs = np.cumsum([0] + scope)
+    sc = [E[name + ".scores"][a:b] for a, b in zip(offs[:-1], offs[1:])]
+    tg = [E[name + ".targets"][a:b] for a, b in zip(offs[:-1], offs[1:])]
+    scaler = tuple(E[name + ".scaler"].tolist()) if name + ".scaler" in E.files else None
+    return sc, tg, scope, scaler, E
+
+
+@pytest.mark.parametrize("name", TOP_SCORES_CASES)
+def test_top_scores_and_calculate_ndcg_against_reference_loops(golden_dir, name):
+    """oracle.top_scores_from_scores / calculate_ndcg_from_scores vs the reference's own evaluate_top_scores
+    (eval.py:76-177) and calculate_ndcg (:329-457) driven with preset scores (tools/make_golden.py gen_top_scores)."""
+    sc, tg, _, scaler, E = top_scores_case(golden_dir, name)
+    first = [s[:, 0] if s.ndim > 1 else s for s in sc]                        # eval.py:125-126, :390-394
+    for ratio in (0.25, 0.1, 0.5):
+        a, b, c, _ = O.top_scores_from_scores(first, tg, ratio)
+        want = E[f"{name}.top_scores_r{ratio}"]
+        assert a == want[0] and abs(b - want[1]) < 1e-15 and c == want[2], (name, ratio)
+    means, stds = scaler if scaler is not None else (None, None)
+    for cut in (0.5, 0.25):
+        nd, kl, _ = O.calculate_ndcg_from_scores(first, tg, cut, means, stds)
+        if "ties" not in name:      # the reference ranks with torch.sort / argsort(stable=False): with tied keys and
+            #                         more than 16 elements its order - hence its NDCG - is implementation-defined
+            assert abs(nd - float(E[f"{name}.ndcg_c{cut}"])) < 1e-7, (name, cut)
+        assert abs(kl - float(E[f"{name}.kl"])) < 1e-7 * max(1.0, abs(kl)), name

@@ -12,7 +12,8 @@ BatchMolGraph as duck-typed MolGraph objects, weights come from a numpy formula
   losses:  MLEloss, ListnetLoss, evidential_ranking, GaussDisLoss, LogCumsumExp, nn.MSELoss
   ranknet: the real factorized_training_loop ('sum_session' and 'accelerate_grad') driven
            with stub data-processor / optimizer objects
-  metrics: reactranker.metrics.NDCG / DCG, train.eval.compute_NDCG, eval's sorted() ordering
+  metrics: reactranker.metrics.NDCG / DCG, train.eval.compute_NDCG, eval's sorted() ordering; ranking_metrics,
+           evaluate_top_scores and calculate_ndcg driven with preset scores
   featurizer: MolGraph(smiles) on molecule descriptions served through a stand-in Chem namespace (tests/fake_rdkit.py)
 
 Usage: python tools/make_golden.py            (writes tests/golden/)
@@ -473,6 +474,71 @@ def gen_eval_metrics():
     print("wrote eval_metrics.npz", {k: v for k, v in out.items() if k.endswith((".top1", ".recall25", ".top25"))})
 
 
+def gen_top_scores():
+    """Drive the reference's own evaluate_top_scores (train/eval.py:76-177) and calculate_ndcg (:329-457) with preset
+    scores: the validation metric of the RankNet epoch driver (run_train_pairwise.py:91-96) and what both test()
+    functions report (test_listwise.py:51-66, test_ranknet.py:59-64)."""
+    import contextlib
+    import io
+    rng = np.random.default_rng(404)
+    out = {}
+    cases = (   # name, scope, queries per model call, decimals of scores, decimals of targets, 2-column output, scaler
+        ("plain", [3, 2, 8, 10, 64, 5, 7, 4, 13], 3, 6, 6, False, None),
+        ("pred_ties", [4, 9, 16, 6, 2, 33, 12], 2, 1, 6, False, None),
+        ("ties", [4, 9, 16, 6, 2, 33], 2, 1, 1, False, None),
+        ("two_col", [6, 11, 2, 40, 9], 2, 6, 6, True, None),
+        ("scaled", [5, 12, 3, 21], 4, 6, 6, False, (0.37, 1.9)),
+        ("two_col_scaled", [7, 10, 30, 4], 3, 6, 6, True, (-1.2, 0.6)),
+    )
+    for name, scope, qpb, dec_s, dec_t, two_col, scaler in cases:
+        M = int(sum(scope))
+        scores = np.round(rng.standard_normal(M) * 1.3, dec_s).astype(np.float32)
+        targets = np.round(rng.standard_normal(M), dec_t).astype(np.float32)
+        if two_col:
+            scores = np.stack([scores, np.abs(rng.standard_normal(M)).astype(np.float32) + 0.1], axis=1)
+        offs = np.concatenate([[0], np.cumsum(scope)])
+
+        class _DP:
+            def generate_batch_querys(self, **kw):
+                assert kw["shuffle_query"] is False and kw["shuffle_batch"] is False
+                for q0 in range(0, len(scope), qpb):
+                    sc = scope[q0:q0 + qpb]
+                    lo, hi = offs[q0], offs[q0 + len(sc)]
+                    X = np.array([["r", "p%d" % i] for i in range(hi - lo)])
+                    yield X, targets[lo:hi].astype(np.float64)[:, None], list(sc), None
+
+        class _Model:
+            def __init__(self):
+                self.at = 0
+
+            def __call__(self, r, p, gpu=None, add_features=None):
+                n = r                      # _StubGraphs.parsing_smiles returns the batch's row count
+                t = torch.tensor(scores[self.at:self.at + n])
+                self.at += n
+                return t
+
+        out[name + ".scope"] = np.asarray(scope, np.int32)
+        out[name + ".scores"], out[name + ".targets"] = scores, targets
+        for ratio in (0.25, 0.1, 0.5):
+            with contextlib.redirect_stdout(io.StringIO()):
+                a, b, c = ref_eval.evaluate_top_scores(_Model(), None, _DP(), _StubGraphs(), ratio=ratio, batch_size=qpb,
+                                                       show_info=False, smiles_list=None, target_name="stdea")
+            out[f"{name}.top_scores_r{ratio}"] = np.asarray([a, b, c], np.float64)
+        for cut in (0.5, 0.25):
+            kw = {}
+            if scaler is not None:
+                kw = dict(means=scaler[0], stds=scaler[1])
+                out[name + ".scaler"] = np.asarray(scaler, np.float64)
+            with contextlib.redirect_stdout(io.StringIO()):
+                nd, kl, order, _ = ref_eval.calculate_ndcg(_Model(), None, _DP(), _StubGraphs(), batch_size=qpb,
+                                                           NDCG_cut=cut, show_info=False, target_name="stdea", **kw)
+            out[f"{name}.ndcg_c{cut}"] = np.float64(nd)
+            out[f"{name}.kl"] = np.float64(kl)
+            out[f"{name}.order_rows"] = np.asarray(order, np.float64)
+    np.savez_compressed(os.path.join(OUT, "top_scores.npz"), **out)
+    print("wrote top_scores.npz", {k: v for k, v in out.items() if ".top_scores_r0.25" in k or ".ndcg_c0.5" in k or k.endswith(".kl")})
+
+
 def gen_train_utils():
     """Learning-rate schedule and optimizer defaults of reactranker/train/utils.py (NoamLR, build_optimizer,
     build_lr_scheduler), produced by the reference classes themselves."""
@@ -609,6 +675,7 @@ if __name__ == "__main__":
     gen_losses()
     gen_metrics()
     gen_eval_metrics()
+    gen_top_scores()
     gen_train_utils()
     gen_standardize()
     gen_featurizer()
