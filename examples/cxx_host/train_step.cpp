@@ -194,12 +194,17 @@ int main(int argc, char** argv) {
     char id[RR_COMM_ID_BYTES];
     rr_comm_t comm = nullptr;
     const int n_ranks = 1, rank = 0;
-    RR_OK_(rr_comm_unique_id(id));
-    RR_OK_(rr_comm_init_rank(&comm, n_ranks, id, rank));
-    for (auto& gb : gbuf)
-      if (gb.first) RR_OK_(rr_allreduce_f32(gb.first, static_cast<int64_t>(gb.second), 1.0f / n_ranks, comm, st));
-    HIP_OK(hipStreamSynchronize(st));
-    RR_OK_(rr_comm_destroy(comm));
+    const int have = rr_comm_unique_id(id);
+    if (have == RR_ERR_UNSUPPORTED) {                     // no RCCL on this machine: forward and backward stand as they are
+      fprintf(stderr, "train_step: no RCCL found (rr_comm_backend() = %d), skipping the gradient exchange\n", rr_comm_backend());
+    } else {
+      RR_OK_(have);
+      RR_OK_(rr_comm_init_rank(&comm, n_ranks, id, rank));
+      for (auto& gb : gbuf)
+        if (gb.first) RR_OK_(rr_allreduce_f32(gb.first, static_cast<int64_t>(gb.second), 1.0f / n_ranks, comm, st));
+      HIP_OK(hipStreamSynchronize(st));
+      RR_OK_(rr_comm_destroy(comm));
+    }
   }
   HIP_OK(hipStreamSynchronize(st));
 

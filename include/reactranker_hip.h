@@ -13,8 +13,11 @@
  *     parameter is documented as host; pointers are borrowed, never retained.
  *   - all floating point is fp32; all indices are int32 (the reference uses int64).
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised.
- *   - return value: RR_OK (0) or a negative rr_status; nothing is thrown, no global state,
- *     re-entrant across streams.  rr_strerror() names a status.
+ *   - return value: RR_OK (0) or a negative rr_status; nothing is thrown; re-entrant across streams.
+ *     rr_strerror() names a status.  State the library keeps between calls, all of it created lazily and
+ *     mutex-guarded: the two non-blocking HIP streams per device that the step plans run their side chains on
+ *     (csrc/plan.hip), the one-time shared-memory attribute of the large-LDS kernels, and the RCCL entry points
+ *     resolved by the first rr_comm_* call.  No results, tensors or workspaces are retained.
  *   - a row index < 0 in any gather table means "skip" (contributes zero); the reference's
  *     padding index 0 is an ordinary row (row 0 = the padding row of BatchMolGraph,
  *     features/featurization.py:255-264) and is gathered like any other.
@@ -168,8 +171,14 @@ typedef enum rr_act { RR_ACT_NONE = 0, RR_ACT_RELU = 1 } rr_act;
  *   FFN Linear/ReLU/Dropout chain                                     models/base_model.py:32-60
  * and their input-gradient GEMMs (dX = dZ * W  ==  same call with w = W^T).
  *
- * Arithmetic: fp32 operands, fp32 accumulate on the f32 MFMA (v_mfma_f32_16x16x4_f32);
- * no reduced-precision path.  Dropout keep-mask = rr_dropout_keep(seed, m*N + n).
+ * Arithmetic: fp32 operands and results, fp32 accumulation.  Two kernels serve the call: with w_packed = 1 every
+ * product runs on the f32 MFMA (v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain); with w_packed = 2 (weights
+ * packed as three exact bf16 terms by rr_pack_weights_f32 / rr_pack_weight_f32 with split = 1) each f32 operand is
+ * written EXACTLY as three bf16 terms and the six products down to 2^-18 |x w| are accumulated in f32 by
+ * v_mfma_f32_16x16x32_bf16 - no operand bit is dropped, what is omitted lies below 2^-26 |x w| per product, and the
+ * measured error against f64 is at or below the f32-MFMA kernel's.  Differences in kind on
+ * that path: an infinite operand, or a finite |x| >= 3.3962e38, turns its output row into NaN (the f32 MFMA gives
+ * +-inf).  Dropout keep-mask = rr_dropout_keep(seed, m*N + n).
  * `residual` may alias `c` (in-place accumulate).  Vector loads need 16-byte aligned base
  * pointers and leading dimensions that are multiples of 4; otherwise a scalar path runs. */
 typedef struct rr_linear_args {
@@ -549,6 +558,7 @@ int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags,
  *   rr_comm_init_rank: collective over all ranks, each on its own current device. */
 typedef void* rr_comm_t;
 #define RR_COMM_ID_BYTES 128
+int rr_comm_backend(void);   /* how RCCL was resolved: 0 not found, 1 symbols already in the process, 2 dlopen("librccl.so.1") */
 int rr_comm_unique_id(void* id);
 int rr_comm_init_rank(rr_comm_t* comm, int n_ranks, const void* id, int rank);
 int rr_comm_destroy(rr_comm_t comm);

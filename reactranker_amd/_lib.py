@@ -187,6 +187,7 @@ _SIGS = {
     "rr_reaction_backward": (i32, [C.POINTER(Model), C.POINTER(Step), c_f32p, C.POINTER(Grads), i32, c_stream]),
     "rr_reaction_saved_f32": (i32, [C.POINTER(Model), C.POINTER(Step), i32, i32, i32, C.POINTER(C.c_void_p), C.POINTER(i64),
                                     C.POINTER(i64)]),
+    "rr_comm_backend": (i32, []),
     "rr_comm_unique_id": (i32, [C.c_void_p]),
     "rr_comm_init_rank": (i32, [C.POINTER(C.c_void_p), i32, C.c_void_p, i32]),
     "rr_comm_destroy": (i32, [C.c_void_p]),

@@ -24,6 +24,7 @@ typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStre
 
 struct Rccl {
   bool tried = false, ok = false;
+  int how = 0;                                            // 1: symbols already in the process, 2: dlopen'ed here
   get_id_fn get_id = nullptr;
   init_rank_fn init_rank = nullptr;
   destroy_fn destroy = nullptr;
@@ -36,18 +37,25 @@ const Rccl& rccl() {
   std::lock_guard<std::mutex> lock(g_rccl_mu);
   if (!g_rccl.tried) {
     g_rccl.tried = true;
+    // RTLD_DEFAULT is a null handle on glibc: "found in the process" must be tracked apart from the handle's value
     void* h = RTLD_DEFAULT;
-    if (dlsym(h, "ncclAllReduce") == nullptr) {
+    bool have = dlsym(RTLD_DEFAULT, "ncclAllReduce") != nullptr;
+    if (!have) {
       h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
       if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      have = h != nullptr;
+      g_rccl.how = 2;
+    } else {
+      g_rccl.how = 1;
     }
-    if (h != nullptr) {
+    if (have) {
       g_rccl.get_id = reinterpret_cast<get_id_fn>(dlsym(h, "ncclGetUniqueId"));
       g_rccl.init_rank = reinterpret_cast<init_rank_fn>(dlsym(h, "ncclCommInitRank"));
       g_rccl.destroy = reinterpret_cast<destroy_fn>(dlsym(h, "ncclCommDestroy"));
       g_rccl.allreduce = reinterpret_cast<allreduce_fn>(dlsym(h, "ncclAllReduce"));
       g_rccl.ok = g_rccl.get_id && g_rccl.init_rank && g_rccl.destroy && g_rccl.allreduce;
     }
+    if (!g_rccl.ok) g_rccl.how = 0;
   }
   return g_rccl;
 }
@@ -67,6 +75,8 @@ __global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, int64
 }  // namespace
 
 extern "C" {
+
+int rr_comm_backend(void) { return rccl().how; }
 
 int rr_comm_unique_id(void* id) {
   RR_CHECK_ARG(id);

@@ -775,11 +775,15 @@ int rr_gather_sum_epi_f32(const float* src, int64_t n_src, int64_t ld_src, const
 #define RR_EPI_LAUNCH(NADD)                                                                                          \
   gather_sum_epi_kernel<NADD><<<grid, 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out, row0_partial, n_partial, \
                                                    ld_partial, E)
+  // The last gather of a backward pass adds the dZ of every earlier iteration: n_adds = depth - 1 there, 0 elsewhere.
+  // Depths 1..6 (the reference's default is 3, BASELINE configs[4] runs 6) get the unrolled form - addends prefetched
+  // beside the gather walk; deeper models take the generic form (run-time addend loop after the gather: same result).
   switch (epi->n_adds) {
     case 0: RR_EPI_LAUNCH(0); break;
     case 1: RR_EPI_LAUNCH(1); break;
     case 2: RR_EPI_LAUNCH(2); break;
     case 3: RR_EPI_LAUNCH(3); break;
+    case 4: RR_EPI_LAUNCH(4); break;
     case 5: RR_EPI_LAUNCH(5); break;
     default: RR_EPI_LAUNCH(-1); break;
   }

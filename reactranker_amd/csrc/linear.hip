@@ -1,4 +1,8 @@
-// Dense layers of the D-MPNN path on the exact-f32 matrix core (v_mfma_f32_16x16x4_f32).
+// Dense layers of the D-MPNN path: f32 GEMMs with fused prologues / epilogues, in two arithmetic forms -
+//   * linear_fast_kernel / wgrad_fast_kernel: every product on the exact-f32 matrix core (v_mfma_f32_16x16x4_f32);
+//     the FFN head, shapes off the fast path, and every GEMM under RR_PLAN_F32_GEMM;
+//   * linear_split_kernel / wgrad_split_kernel (further down): the encoder's GEMMs on the bf16 matrix core through
+//     exact three-term operand splits (x = x0 + x1 + x2 in bf16, six products per f32 multiply, f32 accumulation).
 //
 //   rr_linear_f32        C = dropout(act(residual + bias + [A1|A2] * W^T))   (forward, and dX with W^T)
 //   rr_linear_wgrad_f32  dW = dZ^T * [X1|X2],  dbias = colsum(dZ)            (weight gradients)
@@ -17,8 +21,9 @@
 // stores.  LDS rows are 64 B with the four 16-byte chunks XOR-swizzled so that
 // ds_read_b128 fragment reads are bank-conflict free.
 //
-// f32 MFMA is bit-for-bit an fmaf chain (no reduced precision anywhere); results differ
-// from the CPU reference only by summation order.
+// The f32 MFMA is bit-for-bit an fmaf chain; the split path drops no operand bit (its omitted cross terms lie below
+// 2^-26 |x w| per product) and measures at or below the f32 chain's error against f64 (tests/test_gpu_split.py,
+// tests/test_gpu_headline_kernels.py).  Results differ from the CPU reference by summation order.
 #include "rr_common.h"
 #include <atomic>
 #include <type_traits>
@@ -302,7 +307,8 @@ __device__ unsigned long long* rr_trace_buf = nullptr;
 
 __device__ __attribute__((aligned(16))) const float rr_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
 // a whole row of zeros (4 KiB): "no row" for loaders that walk a row with a wave-uniform column offset
-__device__ __attribute__((aligned(16))) const float rr_zero_row[1024] = {0.f};
+constexpr int RR_ZERO_ROW = 1024;
+__device__ __attribute__((aligned(16))) const float rr_zero_row[RR_ZERO_ROW] = {0.f};
 
 // ------------------------------------------------------------------------ fast path
 // Same math as linear_kernel, for the hot case: every A source 16-byte addressable and W in
@@ -771,7 +777,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #else
   constexpr bool FASTX = false;
 #endif
-  const bool fastx_ok = FASTX && a.k1 <= 960 && a.k2 <= 960;
+  // an interior step reads columns [s*SK, (s+1)*SK) <= k of its row - or of rr_zero_row when the row is missing: the
+  // segment (plus one step of slack for the prefetch) must fit inside that array
+  static_assert(RR_ZERO_ROW % SK == 0 && RR_ZERO_ROW >= 2 * SK, "rr_zero_row must hold whole k-steps");
+  const bool fastx_ok = FASTX && a.k1 + SK <= RR_ZERO_ROW && a.k2 + SK <= RR_ZERO_ROW;
   const float* const xb1 = (rowp1 != nullptr ? rowp1 : rr_zero_row) + fkq * 8;
   const float* const xb2 = (rowp2 != nullptr ? rowp2 : rr_zero_row) + fkq * 8;
   const float* const sb1 = (subp != nullptr ? subp : rr_zero_row) + fkq * 8;

@@ -41,6 +41,29 @@ def parity_log(request):
     return log
 
 
+@pytest.fixture(autouse=True)
+def _parity_table(request):
+    """Collects what the close() / _compare() helpers measured during a -m gpu test (tests/helpers.py: record)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from tests import helpers
+    table = {}
+    helpers.CURRENT = table
+    try:
+        yield
+    finally:
+        helpers.CURRENT = None
+        if table:
+            lines = _PARITY.setdefault(request.node.nodeid, [])
+            # labels often carry a case name: fold them into at most 12 lines, worst first
+            items = sorted(table.items(), key=lambda kv: -kv[1][0])
+            for what, (err, tol) in items[:12]:
+                lines.append(f"max err {err:.3e}" + (f" (bound {tol:g})" if tol is not None else "") + f"  [{what}]")
+            if len(items) > 12:
+                lines.append(f"... and {len(items) - 12} more labels, all below {items[12][1][0]:.3e}")
+
+
 def pytest_sessionfinish(session, exitstatus):
     if not _PARITY:
         return

@@ -57,3 +57,20 @@ def sample_like(a, hidden):
     if hidden >= 300 and a.ndim == 2:
         return a[::7, ::5]
     return a
+
+
+# ---------------------------------------------------------------------------------------------- measured-error recorder
+# tests/conftest.py points CURRENT at the running test's table; the close() / _compare() helpers of the -m gpu tests feed
+# it, so the parity log (profiles/rNN_parity_errors.txt) holds the worst error every parity test MEASURED, next to its bound.
+CURRENT = None
+
+
+def record(what, err, tol=None):
+    """Remember the largest error seen under the label `what` in the running test."""
+    if CURRENT is None:
+        return
+    what = str(what) if what else "value"
+    e = float(err)
+    cur = CURRENT.get(what)
+    if cur is None or not (e <= cur[0]):
+        CURRENT[what] = (e, tol)

@@ -38,3 +38,26 @@ def test_allreduce_over_a_one_rank_communicator(n, scale):
         check(l.rr_allreduce_f32(ptr(y), 0, 1.0, comm, stream()), "empty buffer")
     finally:
         check(l.rr_comm_destroy(comm), "rr_comm_destroy")
+
+
+@pytest.mark.gpu
+def test_rccl_already_in_the_process_is_used_as_is():
+    """A host that links RCCL has ncclAllReduce among its symbols: rr_comm_* must bind to THAT copy (dlsym(RTLD_DEFAULT) -
+    a null handle on glibc, which round 3's resolver mistook for "not found") instead of opening a second one.  A fresh
+    interpreter with librccl preloaded stands in for such a host."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    cands = sorted(glob.glob("/opt/rocm*/lib/librccl.so.1")) + sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")))
+    if not cands:
+        pytest.skip("no librccl on this machine")
+    code = ("import ctypes as C; from reactranker_amd._lib import lib; l = lib(); ident = (C.c_char * 128)(); "
+            "rc = l.rr_comm_unique_id(ident); print('RC', rc, 'HOW', l.rr_comm_backend())")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LD_PRELOAD=cands[0], PYTHONPATH=repo)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "RC 0 HOW 1" in out.stdout, (out.stdout, out.stderr[-2000:])
+    env.pop("LD_PRELOAD")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "RC 0 HOW" in out.stdout, (out.stdout, out.stderr[-2000:])          # nothing preloaded: torch's copy, or dlopen

@@ -227,8 +227,11 @@ def _train_step_vs_fp64_oracle(cfg, Q, Cn, loss_kind, p, atoms_lo, atoms_hi, see
         err = float((gh - gd).abs().max())
         noise = float((g32h[k].double() - gd).abs().max())
         bound = max(5e-5 * scale + 1e-6, 3.0 * noise)
-        log(f"grad {k}: max|err| / max|g| = {err / max(scale, 1e-30):.2e} with the HIP gates dictated to the fp64 oracle "
-            f"({err_nat / max(scale, 1e-30):.2e} against its own gates; fp32 oracle under the same gates: {noise / max(scale, 1e-30):.2e})")
+        if scale < 1e-12:                       # analytically zero (the ranking losses cannot see the output bias)
+            log(f"grad {k}: analytically zero (max|g64| {scale:.1e}); max|err| {err:.2e} absolute (fp32 oracle: {noise:.2e})")
+        else:
+            log(f"grad {k}: max|err| / max|g| = {err / scale:.2e} with the HIP gates dictated to the fp64 oracle "
+                f"({err_nat / scale:.2e} against its own gates; fp32 oracle under the same gates: {noise / scale:.2e})")
         assert err <= bound, f"grad {k}: |err vs fp64 (same gates)| {err:.3e} > {bound:.3e} (fp32 oracle noise {noise:.3e}, scale {scale:.3e})"
     # the step really went through the plan with the shared reactant prefix and dropout acted
     model.eval()

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import helpers as Hh
+
 from reactranker_amd import loss as RL
 from oracle import ref_cpu as O
 
@@ -17,6 +19,7 @@ def close(got, ref, tol=1e-5, what=""):
     ref = ref.detach().cpu().double().numpy().reshape(-1) if torch.is_tensor(ref) else np.asarray(ref, np.float64).reshape(-1)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     err = np.max(np.abs(got - ref) / (1 + np.abs(ref))) if got.size else 0
+    Hh.record(what, err, tol)
     assert err <= tol, f"{what}: err {err:.3e}"
 
 

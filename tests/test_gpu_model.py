@@ -26,6 +26,7 @@ def close(got, ref, tol=1e-5, what=""):
     ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     err = np.max(np.abs(got - ref) / (1 + np.abs(ref))) if got.size else 0.0
+    Hh.record(what, err, tol)
     assert err <= tol, f"{what}: err {err:.3e} > {tol}"
     return err
 
@@ -53,6 +54,7 @@ def check_grads(model, d, prefix, H, tol=5e-5):
         # analytically zero (e.g. ListMLE's output bias: sum_j dL/ds_j = 0 per list)
         err = float(np.max(np.abs(got.astype(np.float64) - ref)))
         bound = tol * float(np.abs(ref).max()) + 1e-6
+        Hh.record("grad " + prefix + " (worst tensor, |err| / (max|g| + 2e-2))", err / (float(np.abs(ref).max()) + 2e-2), None)
         assert err <= bound, f"{key}: |err| {err:.3e} > {bound:.3e}"
     assert seen > 0, prefix
 

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import helpers as Hh
+
 from reactranker_amd import functions as Fn
 from reactranker_amd import _lib
 from oracle import dropout_ref
@@ -24,6 +26,7 @@ def close(got, ref, tol=TOL, what=""):
     if got.size == 0:
         return
     err = np.max(np.abs(got - ref) / (1 + np.abs(ref)))
+    Hh.record(what, err, tol)
     assert err <= tol, f"{what}: err {err:.3e} > {tol}"
 
 

@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import helpers as Hh
+
 from reactranker_amd import functions as Fn
 from reactranker_amd import _lib
 from reactranker_amd._lib import PackDesc, check, lib, ptr, stream
@@ -84,6 +86,8 @@ def _err(out, ref, den):
 def _compare(o32, osp, ref, den, what, north_star=True):
     m32, a32 = _err(o32, ref, den)
     msp, asp = _err(osp, ref, den)
+    Hh.record(what + " | split max err / sum|ab|", msp, 2e-6)
+    Hh.record(what + " | f32-MFMA max err / sum|ab|", m32)
     assert asp <= 1.25 * a32 + 1e-12, f"{what}: mean error split {asp:.3e} vs f32 {a32:.3e}"
     assert msp <= 2.0 * m32 + 1e-12, f"{what}: max error split {msp:.3e} vs f32 {m32:.3e}"
     assert msp <= 2e-6, f"{what}: max error {msp:.3e} (relative to sum |a b|)"
