@@ -121,7 +121,9 @@ class Runner:
                                  ffn_last_layer=cfg["last"], task_type=cfg["task_type"], add_features_dim=1).to(device)
         self.model.train()
         # the reference's build_optimizer / NoamLR (train/utils.py) through their mirrors; fused Adam = same update, one kernel
-        self.opt = build_optimizer(self.model, fused=not args.foreach_adam)
+        # default: the library's one-launch Adam (HipAdam: torch.optim.Adam's formula and state); --torch-fused-adam /
+        # --foreach-adam select torch's own kernels for comparison
+        self.opt = build_optimizer(self.model, fused=False if args.foreach_adam else (True if getattr(args, "torch_fused_adam", False) else None))
         self.bucket = GradBucket(self.model.parameters())
         if world > 1:
             self.bucket.attach()                          # gradients are written straight into the all-reduce buffer
@@ -392,7 +394,8 @@ def main():
     ap.add_argument("--no-side-stream", action="store_true", help="run weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="run the reactant encoder on the main stream")
     ap.add_argument("--aux-backward", action="store_true", help="also run the reactant encoder's backward on the aux stream")
-    ap.add_argument("--foreach-adam", action="store_true", help="torch's multi-kernel Adam instead of its fused single-kernel one")
+    ap.add_argument("--foreach-adam", action="store_true", help="torch's multi-kernel Adam instead of the library's one-launch Adam")
+    ap.add_argument("--torch-fused-adam", action="store_true", help="torch's fused Adam instead of the library's one-launch Adam")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -521,6 +524,7 @@ def main():
 
     extra = {}
     if not args.no_fwd_only:                              # report fwd+loss and fwd+loss+bwd separately
+        from reactranker_amd import eval as RE
         R.model.eval()
         with torch.no_grad():                             # upload the de-duplication maps outside the timed loop
             for b in pool:
@@ -534,6 +538,47 @@ def main():
         R.fence()
         extra["fwd_loss_queries_per_s"] = round(world * args.steps * cfg["queries"] / (time.perf_counter() - tf0), 1)
         extra["fwd_loss_note"] = "eval mode (no dropout): forward + loss only; reactant encoder runs once per distinct reactant"
+        # the per-epoch validation of the reference (train/eval.py:475-555: one forward per query + Python lists) as it runs
+        # here: one forward per 64-query step + ONE rr_ranking_metrics_f32 launch (all 12 statistics of every query)
+        with torch.no_grad():
+            for i in range(2):
+                b = pool[i % len(pool)]
+                RE.ranking_stats(R.model(b["r"], b["p"], gpu=local, add_features=b["add"]), b["scope"], b["targets"], local)
+        R.fence()
+        mev = []
+        tv0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(args.steps):
+                b = pool[i % len(pool)]
+                out = R.model(b["r"], b["p"], gpu=local, add_features=b["add"])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                RE.ranking_stats(out, b["scope"], b["targets"], local)
+                e1.record()
+                mev.append((e0, e1))
+        R.fence()
+        tv = time.perf_counter() - tv0
+        mus = [a.elapsed_time(b_) * 1e3 for a, b_ in mev]
+        extra["validation"] = dict(
+            queries_per_s=round(world * args.steps * cfg["queries"] / tv, 1), ms_per_step=round(tv / args.steps * 1e3, 3),
+            ranking_metrics_launch_us=dict(median=round(float(np.median(mus)), 1), min=round(min(mus), 1), max=round(max(mus), 1)),
+            note="eval-mode forward of a 64-query step + one rr_ranking_metrics_f32 launch (stable sort by score and by target, "
+                 "top-1 / top-25% / recall / NDCG / evaluate_top_scores / calculate_ndcg statistics of every query, one "
+                 "wavefront per query); HIP events around the metrics launch on the compute stream")
+        if not args.no_profile:
+            # roofline of the forward-only path: per-op issue with HIP events around every heavy launch (eval mode, reactant
+            # de-duplication on, the product / distinct-reactant encoders overlapping on two streams as in production)
+            Fn.Profiler.start()
+            with torch.no_grad():
+                for i in range(min(args.steps, 6)):
+                    b = pool[i % len(pool)]
+                    R.model(b["r"], b["p"], gpu=local, add_features=b["add"])
+            R.fence()
+            rf, rfg, ktf = summarise(Fn.Profiler.stop(), {})
+            if rf:
+                rf["note"] = ("eval-mode forward only (what validation and inference run): HIP events around every heavy launch, "
+                              "issued per op; traffic not collected for this pass")
+            extra["roofline_fwd"], extra["roofline_fwd_gather"], extra["kernels_fwd"] = rf, rfg, ktf
         R.model.train()
 
     # timed region: kernels of the three streams overlap, so a kernel's launch duration includes the time it
@@ -596,6 +641,17 @@ def main():
             rd = SH.ShardSet(shard_paths)
             n = len(rd)
             log(f"streaming {n} distinct steps from {len(shard_paths)} shard file(s)")
+            # Two untimed steps through the streaming path first, like the warm-up of the resident region: the first
+            # streamed step allocates what a resident step never needs (the device-side f_bonds rebuild, a workspace for a
+            # step a few per cent larger than the pool's) - 37 ms on this run's box, ~95 ms on the round-3 driver box, which
+            # is ALL of the 0.925-0.975x the 200-step leg showed there (its per-step median was already below the resident
+            # region's).  A real epoch is 1563 steps: the first one is noise there, it was 8 % of a 200-step leg.
+            warm = SH.StepPrefetcher(rd, device, range(min(2, n)), depth=2)
+            warm.prime()
+            for wb in warm:
+                R.train_step(wb)
+            warm.close()
+            R.fence()
             pf = SH.StepPrefetcher(rd, device, range(n), depth=3)
             startup = pf.prime()                          # start-up latency of the pipeline, reported, not timed
             it = iter(pf)
@@ -614,13 +670,15 @@ def main():
                          shard_gb_per_rank=round(sum(os.path.getsize(p) for p in shard_paths) / 1e9, 3),
                          step_mb=round(rd.max_step_bytes / 1e6, 2), h2d_gb_per_rank=round(pf.bytes_copied / 1e9, 3),
                          consumer_wait_s=round(pf.wait_s, 4), prefetch_startup_s=round(startup, 4), pack_s=round(t_shards, 2),
-                         page_cache="hot",
+                         page_cache="hot", warmup_steps=min(2, n),
                          note="every step read once from shard files written seconds earlier by this run, i.e. served from the "
                               "page cache, not from the disk (page cache -> pinned staging -> one H2D copy per step on a "
                               "copy stream, 3 slots); only the 22 bond columns of f_bonds and the distinct reactants' "
                               "features travel, the rest is rebuilt on the device; same model / optimizer state continues "
                               "from the timed region")
             log(f"epoch stream: {e_secs / n * 1e3:.2f} ms/step, {qps_e:.0f} queries/s")
+            log("epoch stream detail: " + json.dumps({k: epoch[k] for k in ("vs_resident", "step_ms", "slowest_steps", "consumer_wait_s",
+                                                                           "prefetch_startup_s", "h2d_gb_per_rank")}))
         except Exception as e:                            # noqa: BLE001
             epoch = dict(skipped=f"{type(e).__name__}: {e}")
             log(f"epoch stream failed: {epoch['skipped']}")

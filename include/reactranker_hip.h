@@ -239,7 +239,7 @@ int rr_pack_weight_f32(const float* src, int64_t ld_src, int transpose, int rows
                        float* dst, rr_stream_t stream);
 
 /* rr_pack_weight_f32 for up to RR_MAX_PACK weights in one launch (`descs` is a HOST array). */
-#define RR_MAX_PACK 16
+#define RR_MAX_PACK 24
 typedef struct rr_pack_desc {
   const float* src;  int64_t ld_src;  int transpose, rows, c0, k1, k2;
   float* dst;
@@ -301,6 +301,19 @@ int rr_relu_bwd_sum_f32(const float* dy, const float* y, float scale, const floa
 /* out = alpha * a + beta * b   (b may be NULL).  diff = p_h - r_h (models/base_model.py:168). */
 int rr_axpby_f32(float alpha, const float* a, float beta, const float* b, float* out,
                  int64_t n, rr_stream_t stream);
+
+/* Adam update of up to RR_MAX_ADAM tensors in ONE launch (ABI revision 6) - the optimizer the reference builds
+ * (train/utils.py:100-113: torch.optim.Adam, lr 1e-4, weight_decay 0; betas / eps torch's defaults), per element:
+ *   g' = g + weight_decay * p;  m = m + (g' - m) * (1 - beta1);  v = beta2 * v + (1 - beta2) * g' * g'
+ *   p -= (lr / (1 - beta1^step)) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * i.e. torch's own formula (fused_adam_utils.cuh: scalars in double, each element rounded to f32 once), with `step` the
+ * 1-based count of this update.  `descs` is a HOST array;
+ * a tensor with g == NULL is skipped.  torch's multi-tensor kernel walks 64k-element chunks, ~20 workgroups for this
+ * model's 0.8 M parameters (45 us on MI355X); here a workgroup takes 1024 elements. */
+#define RR_MAX_ADAM 64
+typedef struct rr_adam_tensor { float* p; const float* g; float* m; float* v; int64_t n; } rr_adam_tensor;
+int rr_adam_step_f32(const rr_adam_tensor* descs, int n_tensors, int64_t step, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, rr_stream_t stream);
 
 /* FFN output heads (models/base_model.py:61-106), applied to raw[M, N] -> out[M, N]. */
 typedef enum rr_head {
@@ -500,9 +513,13 @@ enum { RR_STEP_PLAIN = 0,    /* encoder(r) on the full reactant batch */
        RR_STEP_DEDUP = 1,    /* dropout inactive: `r` holds the DISTINCT reactants, amap / amap_t map product atoms to them */
        RR_STEP_PREFIX = 2 }; /* train mode: `u` holds the distinct reactants, only the deterministic prefix is shared */
 enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2,
-       RR_PLAN_F32_GEMM = 4,
-       RR_PLAN_AUX_BACKWARD = 8 };   /* reactant-encoder backward on the aux stream beside the product pass */   /* encoder GEMMs on the f32 matrix core instead of the three-bf16-term path (w_packed = 2);
-                                    forward and backward of a step must agree on it (it changes the workspace layout) */
+       RR_PLAN_F32_GEMM = 4,         /* encoder GEMMs on the f32 matrix core instead of the three-bf16-term path (w_packed = 2);
+                                        forward and backward of a step must agree on it (it changes the workspace layout) */
+       RR_PLAN_AUX_BACKWARD = 8,     /* reactant-encoder backward on the aux stream beside the product pass */
+       RR_PLAN_TRAIN = 16 };         /* a backward WILL follow: rr_reaction_forward also packs the transposed weights of the
+                                        input-gradient GEMMs, in the same launch as the forward's packs, so the backward
+                                        starts with its first GEMM instead of a pack.  Layout-changing like RR_PLAN_F32_GEMM:
+                                        pass the same flags to both calls (ABI revision 6). */
 
 typedef struct rr_step {
   rr_graph p, r, u;

@@ -77,7 +77,7 @@ class GatherEpi(C.Structure):
 RR_MAX_FFN = 8
 RR_G_FFN0 = 6
 RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
-RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM, RR_PLAN_AUX_BACKWARD = 1, 2, 4, 8
+RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM, RR_PLAN_AUX_BACKWARD, RR_PLAN_TRAIN = 1, 2, 4, 8, 16
 
 
 class Graph(C.Structure):
@@ -187,6 +187,7 @@ _SIGS = {
     "rr_reaction_backward": (i32, [C.POINTER(Model), C.POINTER(Step), c_f32p, C.POINTER(Grads), i32, c_stream]),
     "rr_reaction_saved_f32": (i32, [C.POINTER(Model), C.POINTER(Step), i32, i32, i32, C.POINTER(C.c_void_p), C.POINTER(i64),
                                     C.POINTER(i64)]),
+    "rr_adam_step_f32": (i32, [C.c_void_p, i32, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_stream]),
     "rr_comm_backend": (i32, []),
     "rr_comm_unique_id": (i32, [C.c_void_p]),
     "rr_comm_init_rank": (i32, [C.POINTER(C.c_void_p), i32, C.c_void_p, i32]),
@@ -199,6 +200,11 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
+class AdamTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
+
+
+RR_MAX_ADAM = 64
 ABI_VERSION = 6
 (RR_SAVED_R_MSG, RR_SAVED_R_H, RR_SAVED_P_MSG, RR_SAVED_P_H, RR_SAVED_D_MSG, RR_SAVED_D_HID, RR_SAVED_VECS, RR_SAVED_FFN_H,
  RR_SAVED_R_MSG0_U, RR_SAVED_R_Z1_U) = range(10)

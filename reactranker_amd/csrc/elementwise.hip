@@ -1,6 +1,8 @@
 // Elementwise kernels: ReLU/dropout backward, axpby, FFN output heads; plus the ABI's
 // status/version helpers.  All HBM-bound streaming kernels with 16-byte lanes.
 #include "rr_common.h"
+#include <math.h>
+#include <string.h>
 
 namespace {
 
@@ -168,9 +170,73 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------- Adam over many tensors, one launch
+struct AdamMany {
+  rr_adam_tensor t[RR_MAX_ADAM];
+  int32_t first_block[RR_MAX_ADAM + 1];     // prefix sum of the tensors' 1024-element blocks
+  int n;
+  double step_size, bc2_sqrt, beta2, one_m_b1, one_m_b2, eps, wd;
+};
+
+// torch's fused Adam keeps its scalars in double, so each element's update is double arithmetic rounded to f32 once
+// (fused_adam_utils.cuh); the same here - 0.8 M elements, the kernel stays launch-latency-sized.
+__global__ void __launch_bounds__(256) adam_many_kernel(const AdamMany A) {
+  const int b = blockIdx.x;
+  int ti = 0;
+  while (ti + 1 < A.n && b >= A.first_block[ti + 1]) ++ti;          // (block-uniform: a scalar loop over <= 64 entries)
+  const rr_adam_tensor T = A.t[ti];
+  const int64_t base = static_cast<int64_t>(b - A.first_block[ti]) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = base + u * 256 + threadIdx.x;
+    if (i < T.n) {
+      const float pf = T.p[i];
+      double g = static_cast<double>(T.g[i]);
+      if (A.wd != 0.0) g = g + A.wd * static_cast<double>(pf);
+      const float gf = static_cast<float>(g);                          // (torch: grad += weight_decay * param, an f32 value)
+      const float m = static_cast<float>(static_cast<double>(T.m[i]) + A.one_m_b1 * (static_cast<double>(gf) - static_cast<double>(T.m[i])));
+      const float v = static_cast<float>(A.beta2 * static_cast<double>(T.v[i]) + A.one_m_b2 * static_cast<double>(gf) * static_cast<double>(gf));
+      const double denom = sqrt(static_cast<double>(v)) / A.bc2_sqrt + A.eps;
+      T.m[i] = m;
+      T.v[i] = v;
+      T.p[i] = static_cast<float>(static_cast<double>(pf) - A.step_size * static_cast<double>(m) / denom);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rr_adam_step_f32(const rr_adam_tensor* descs, int n_tensors, int64_t step, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, rr_stream_t stream) {
+  RR_CHECK_ARG(descs && n_tensors >= 0 && n_tensors <= RR_MAX_ADAM && step >= 1);
+  RR_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0);
+  AdamMany A;
+  memset(&A, 0, sizeof(A));
+  int64_t blocks = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    const rr_adam_tensor& t = descs[i];
+    if (t.g == nullptr || t.n == 0) continue;
+    RR_CHECK_ARG(t.p && t.m && t.v && t.n > 0);
+    A.t[A.n] = t;
+    A.first_block[A.n] = static_cast<int32_t>(blocks);
+    blocks += (t.n + 1023) / 1024;
+    if (blocks > (int64_t(1) << 30)) return RR_ERR_UNSUPPORTED;
+    ++A.n;
+  }
+  if (A.n == 0) return RR_OK;
+  A.first_block[A.n] = static_cast<int32_t>(blocks);
+  const double bc1 = 1.0 - pow(beta1, static_cast<double>(step));
+  const double bc2 = 1.0 - pow(beta2, static_cast<double>(step));
+  A.step_size = lr / bc1;
+  A.bc2_sqrt = sqrt(bc2);
+  A.beta2 = beta2; A.eps = eps; A.wd = weight_decay;
+  A.one_m_b1 = 1.0 - beta1;
+  A.one_m_b2 = 1.0 - beta2;
+  adam_many_kernel<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(A);
+  return rr_launch_status();
+}
 
 const char* rr_strerror(int status) {
   switch (status) {

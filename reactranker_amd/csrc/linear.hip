@@ -2043,6 +2043,48 @@ int launch_linear(const LinearParams& P, hipStream_t s, bool fast) {
 
 inline bool vec_ok(const float* p, int64_t ld) { return p && rr_aligned16(p) && (ld % 4 == 0); }
 
+// C[m, n] = bias[n] + sum_k A[m, k] * W[n, k] for a handful of output columns (the FFN's last layer: N = task_num <= 8,
+// models/base_model.py:57): 16 lanes per row, the row in registers, a shuffle tree per output.  The MFMA kernels spend a
+// 64-column tile (and ~20 us of fixed cost at one row per molecule) on these one or two columns.
+constexpr int RD_MAXK = 1024;                 // 16 lanes x 4 floats x 16 chunks
+__global__ void __launch_bounds__(256) linear_rowdot_kernel(const float* __restrict__ a, int64_t lda, int k,
+                                                            const float* __restrict__ w, int64_t ldw,
+                                                            const float* __restrict__ bias, int64_t M, int N,
+                                                            float* __restrict__ c, int64_t ldc) {
+  const int l16 = threadIdx.x & 15;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4);
+  const bool live = row < M;
+  const float* ar = a + (live ? row : 0) * lda;
+  f32x4 x[RD_MAXK / 64];
+  const int nch = (k + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < RD_MAXK / 64; ++i) {
+    const int kk = i * 64 + l16 * 4;
+    x[i] = (i < nch && kk < k) ? *reinterpret_cast<const f32x4*>(ar + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int n = 0; n < N; ++n) {
+    const float* wr = w + static_cast<int64_t>(n) * ldw;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < RD_MAXK / 64; ++i) {
+      const int kk = i * 64 + l16 * 4;
+      if (i < nch && kk < k) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + kk);
+        acc += x[i][0] * wv[0];
+        acc += x[i][1] * wv[1];
+        acc += x[i][2] * wv[2];
+        acc += x[i][3] * wv[3];
+      }
+    }
+    acc += __shfl_xor(acc, 8, 16);
+    acc += __shfl_xor(acc, 4, 16);
+    acc += __shfl_xor(acc, 2, 16);
+    acc += __shfl_xor(acc, 1, 16);
+    if (live && l16 == 0) c[row * ldc + n] = acc + (bias ? bias[n] : 0.f);
+  }
+}
+
+
 #ifndef RR_EPI_MODE
 #define RR_EPI_MODE 1
 #endif
@@ -2139,6 +2181,15 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   P.keep_scale = 1.0f / (1.0f - a.drop_p);
 
   hipStream_t s = static_cast<hipStream_t>(stream);
+  P.w_k1_off = a.w_packed ? r16(a.k1) : a.k1;         // (packed rows are r16(k1) + r16(k2) floats: with k2 = 0 this is the row pitch)
+  // a handful of output columns off one plain operand, nothing fused (the FFN's last layer): the row-dot kernel
+  if (a.N <= 8 && a.w_packed == 1 && a.k2 == 0 && a.k1 % 4 == 0 && a.k1 <= RD_MAXK && (P.flags & F_A1_VEC) && !a.a1_idx && !a.a1_sub &&
+      !a.a_mask && !a.a_mask_bits && !a.residual && a.act == RR_ACT_NONE && a.drop_p == 0.f && !a.c_pre && !a.dz_out &&
+      !a.colsum_partial && !a.mask_bits_out && !getenv("RR_NO_ROWDOT")) {
+    linear_rowdot_kernel<<<static_cast<unsigned>((a.M + 15) / 16), 256, 0, s>>>(a.a1, a.lda1, a.k1, a.w, P.w_k1_off, a.bias, a.M,
+                                                                               a.N, a.c, a.ldc);
+    return rr_launch_status();
+  }
   // fast path: packed W, every present A source 16-byte addressable, vector epilogue
   bool fast = a.w_packed && (P.flags & F_EPI_VEC) && (!a.c_pre || (P.flags & F_PRE_VEC));
   if (a.k1 > 0 && !(P.flags & F_A1_VEC)) fast = false;

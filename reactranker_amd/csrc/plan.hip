@@ -86,6 +86,7 @@ struct Ctx {
   Arena ar;
   Streams s;
   bool use_side, use_aux, aux_bwd;
+  bool train;                         // RR_PLAN_TRAIN: the forward packs the backward's transposed weights too
   hipStream_t cur;                    // stream of the backward chain being enqueued (main, or aux for the reactant pass)
   bool split;                         // encoder GEMMs on the bf16 matrix core (three exact bf16 terms per f32 operand)
   rr_pack_desc pq[RR_MAX_PACK];       // weight packs waiting for flush_packs()
@@ -226,8 +227,13 @@ struct FfnSaved {
 struct PackedW {
   Packed enc_wi, enc_wh, enc_wo, dif_wi, dif_wh, dif_wo, ffn[RR_MAX_FFN];
 };
+struct PackedT {                     // transposed weights of the input-gradient GEMMs (dX = dZ * W): packed in one launch
+  Packed ffn[RR_MAX_FFN];
+  Packed dif_wo_x, dif_wo_a, dif_wh, dif_wi, enc_wh, enc_wo;
+};
 struct Plan {
   PackedW pk;
+  PackedT T;                         // filled by the forward under RR_PLAN_TRAIN, by the backward otherwise
   EncSaved r, p;
   DiffSaved d;
   FfnSaved f;
@@ -398,6 +404,23 @@ void ffn_forward(Ctx& c, const rr_model& m, const PackedW& pk, int64_t M, float 
   if (m.head != 0) RR_TRY(c, rr_head_fwd_f32(S.raw, M, L.out, m.head, out, st));
 }
 
+int ffn_dx_rows(const rr_model& m, int li);
+
+// every transposed weight of the backward, queued for ONE pack launch
+void pack_transposes(Ctx& c, const rr_model& m, PackedT& T, hipStream_t main) {
+  const int H = m.H;
+  memset(&T, 0, sizeof(T));
+  for (int li = 0; li < m.n_ffn; ++li) T.ffn[li] = pack(c, m.ffn[li], 1, ffn_dx_rows(m, li), 0, m.ffn[li].out, 0, main, false);
+  if (m.diff_depth > 0) {
+    T.dif_wo_x = pack(c, m.dif_wo, 1, H, 0, H, 0, main);
+    T.dif_wo_a = pack(c, m.dif_wo, 1, H, H, H, 0, main);
+  }
+  if (m.diff_depth > 1) T.dif_wh = pack(c, m.dif_wh, 1, H, 0, H, 0, main);
+  T.dif_wi = pack(c, m.dif_wi, 1, H, 0, H, 0, main);
+  if (m.depth > 1) T.enc_wh = pack(c, m.enc_wh, 1, H, 0, H, 0, main);
+  T.enc_wo = pack(c, m.enc_wo, 1, H, m.atom_fdim, H, 0, main);
+}
+
 void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
   const int H = m.H;
   const float p = s.drop_p;
@@ -410,7 +433,8 @@ void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
   if (m.diff_depth > 1) P.pk.dif_wh = pack(c, m.dif_wh, 0, H, 0, H, m.bond_fdim, main);
   if (m.diff_depth > 0) P.pk.dif_wo = pack(c, m.dif_wo, 0, H, 0, H, H, main);
   for (int li = 0; li < m.n_ffn; ++li) P.pk.ffn[li] = pack(c, m.ffn[li], 0, m.ffn[li].out, 0, m.ffn[li].in, 0, main, false);
-  flush_packs(c, main);                                  // every forward weight in one launch
+  if (c.train) pack_transposes(c, m, P.T, main);         // ... and, when a backward follows, its transposes ride along
+  flush_packs(c, main);                                  // every weight of the step in one launch
   hipStream_t rs = c.use_aux ? c.s.aux : main;
   if (c.launch && c.use_aux) c.fail(stream_wait(c.s.aux, main));
   const uint64_t s_r = site_seed(s.seed, 1), s_p = site_seed(s.seed, 2);
@@ -426,10 +450,6 @@ void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
 
 // ------------------------------------------------------------------------------------------------ backward pieces
 struct EncGrads { float *wi, *bi, *wh, *bh, *wo, *bo; };
-struct PackedT {                     // transposed weights of the input-gradient GEMMs (dX = dZ * W): packed in one launch
-  Packed ffn[RR_MAX_FFN];
-  Packed dif_wo_x, dif_wo_a, dif_wh, dif_wi, enc_wh, enc_wo;
-};
 
 // d message = adjoint of the bond message (one gather over b2b_t; row 0 from the GEMM's weighted column sums)
 float* bond_adjoint(Ctx& c, const rr_graph& g, int H, const float* d_min, const float* part, hipStream_t st) {
@@ -740,19 +760,12 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
   const int H = m.H;
   const float p = s.drop_p;
   hipStream_t main = c.s.main;
-  // every transposed weight of the backward in ONE pack launch
-  PackedT T;
-  memset(&T, 0, sizeof(T));
-  for (int li = 0; li < m.n_ffn; ++li) T.ffn[li] = pack(c, m.ffn[li], 1, ffn_dx_rows(m, li), 0, m.ffn[li].out, 0, main, false);
-  if (m.diff_depth > 0) {
-    T.dif_wo_x = pack(c, m.dif_wo, 1, H, 0, H, 0, main);
-    T.dif_wo_a = pack(c, m.dif_wo, 1, H, H, H, 0, main);
+  // the transposed weights of the input-gradient GEMMs: packed by the forward (RR_PLAN_TRAIN), or here in ONE launch
+  if (!c.train) {
+    pack_transposes(c, m, P.T, main);
+    flush_packs(c, main);
   }
-  if (m.diff_depth > 1) T.dif_wh = pack(c, m.dif_wh, 1, H, 0, H, 0, main);
-  T.dif_wi = pack(c, m.dif_wi, 1, H, 0, H, 0, main);
-  if (m.depth > 1) T.enc_wh = pack(c, m.enc_wh, 1, H, 0, H, 0, main);
-  T.enc_wo = pack(c, m.enc_wo, 1, H, m.atom_fdim, H, 0, main);
-  flush_packs(c, main);
+  const PackedT& T = P.T;
   int64_t ld_dvecs = 0;
   float* dvecs = ffn_backward(c, m, s.p.M, p, P.f, dout, G, T, &ld_dvecs);
   const int32_t* xsi = s.mode == RR_STEP_DEDUP ? s.amap : nullptr;
@@ -831,13 +844,15 @@ void rr_abi_plan_struct_sizes(size_t* graph, size_t* model, size_t* step, size_t
 size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
   if (check(model, step) != RR_OK) return 0;
   size_t need = 0;
-  for (int split = 0; split < 2; ++split) {            // either GEMM path (RR_PLAN_F32_GEMM) must fit
+  for (int v = 0; v < 4; ++v) {                        // either GEMM path (RR_PLAN_F32_GEMM), with or without RR_PLAN_TRAIN, must fit
     Ctx c;
     c.launch = false; c.status = RR_OK; c.ar.base = nullptr; c.ar.off = 0; c.ar.cap = 0; c.ar.overflow = false; c.npq = 0;
     c.use_side = c.use_aux = false;
     c.aux_bwd = false;
     c.cur = nullptr;
-    c.split = split != 0;
+    c.s.main = c.s.side = c.s.aux = nullptr;
+    c.split = (v & 1) != 0;
+    c.train = (v & 2) != 0;
     Plan P;
     memset(&P, 0, sizeof(P));
     forward_all(c, *model, *step, P);
@@ -860,6 +875,7 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
   c.split = (flags & RR_PLAN_F32_GEMM) == 0;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
+  c.train = (flags & RR_PLAN_TRAIN) != 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -895,6 +911,7 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
   c.split = (flags & RR_PLAN_F32_GEMM) == 0;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
+  c.train = (flags & RR_PLAN_TRAIN) != 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -925,6 +942,7 @@ int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags,
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
   c.split = (flags & RR_PLAN_F32_GEMM) == 0;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
+  c.train = (flags & RR_PLAN_TRAIN) != 0;
   c.s.main = c.s.side = c.s.aux = nullptr;
   c.cur = nullptr;
   Plan P;

@@ -12,6 +12,8 @@ Reference sites are cited per function (paths relative to the reference root).
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Optional
 
@@ -1023,9 +1025,10 @@ class StepPlan:
         return M, S, keep
 
     @staticmethod
-    def flags() -> int:
+    def flags(train: bool = False) -> int:
         return ((0 if SideStream.enabled else _lib.RR_PLAN_NO_SIDE_STREAM) | (0 if AuxStream.enabled else _lib.RR_PLAN_NO_AUX_STREAM) |
-                (0 if SplitGemm.enabled else _lib.RR_PLAN_F32_GEMM) | (_lib.RR_PLAN_AUX_BACKWARD if AuxStream.backward else 0))
+                (0 if SplitGemm.enabled else _lib.RR_PLAN_F32_GEMM) | (_lib.RR_PLAN_AUX_BACKWARD if AuxStream.backward else 0) |
+                (_lib.RR_PLAN_TRAIN if (train and not os.environ.get("RR_NO_TRAIN_PACK")) else 0))
 
 
 class ReactionModelFn(torch.autograd.Function):
@@ -1045,7 +1048,8 @@ class ReactionModelFn(torch.autograd.Function):
                 raise RuntimeError("rr_reaction_workspace_bytes rejected the step (inconsistent model / batch shapes)")
             ws = _WorkspacePool.take(nbytes, pg.device)
             S.workspace, S.workspace_bytes = C.c_void_p(ws.data_ptr()), nbytes
-            flags = StepPlan.flags()                    # the backward must lay the workspace out the same way
+            # the backward must lay the workspace out the same way; when one will come, the forward packs its weights too
+            flags = StepPlan.flags(train=any(ctx.needs_input_grad))
             check(lib().rr_reaction_forward(C.byref(M), C.byref(S), flags, stream()), "rr_reaction_forward")
             ctx.plan = (M, S, keep, ws, out, flags)
             if StepPlan.keep_last:

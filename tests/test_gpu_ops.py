@@ -451,3 +451,46 @@ def test_segment_mean_backward_with_the_fused_mask():
     want = Fn.relu_bwd(Fn.segment_mean_bwd(dout, g, H, F, p, 77), plain, 1.0 / (1.0 - p))
     assert torch.equal(Fn.segment_mean_bwd(dout, g, H, F, p, 77, mask=hid, mask_scale=1.0 / (1.0 - p)), want)
     assert torch.equal(Fn.segment_mean_bwd(dout, g, H, F, p, 77, mask=plain, mask_scale=1.0 / (1.0 - p)), want)
+
+
+def test_hip_adam_is_torch_adam_in_one_launch():
+    """train_utils.HipAdam (rr_adam_step_f32) against torch.optim.Adam on the same gradients: parameters and moments over
+    five steps with a changing learning rate (NoamLR writes param_groups[0]['lr']), a parameter that gets no gradient in
+    some steps (skipped, its step count stays behind), weight decay, and the state_dict layout torch's Adam has."""
+    from reactranker_amd.train_utils import HipAdam
+    torch.manual_seed(0)
+    shapes = [(300, 83), (300,), (300, 300), (1, 300), (7,), (2049,)]
+    for wd in (0.0, 0.01):
+        P1 = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+        P2 = [torch.nn.Parameter(p.detach().clone()) for p in P1]
+        o1 = HipAdam([{"params": P1, "lr": 1e-4, "weight_decay": wd}])
+        o2 = torch.optim.Adam([{"params": P2, "lr": 1e-4, "weight_decay": wd}])
+        for step in range(5):
+            lr = 1e-4 * (1 + step)
+            o1.param_groups[0]["lr"] = o2.param_groups[0]["lr"] = lr
+            for i, (a, b) in enumerate(zip(P1, P2)):
+                if i == 4 and step in (1, 3):
+                    a.grad = b.grad = None                               # skipped like torch skips it
+                    continue
+                g = torch.randn_like(a) * (10.0 ** (step - 3))
+                a.grad, b.grad = g.clone(), g.clone()
+            o1.step()
+            o2.step()
+            for i, (a, b) in enumerate(zip(P1, P2)):
+                scale = float(b.detach().abs().max())
+                err = float((a.detach() - b.detach()).abs().max())
+                Hh.record(f"HipAdam vs torch.optim.Adam, parameters (wd {wd})", err / scale, 1e-6)
+                assert err <= 1e-6 * scale, (wd, step, i, err)
+                for key in ("exp_avg", "exp_avg_sq"):
+                    m1, m2 = o1.state[a][key], o2.state[b][key]
+                    assert float((m1 - m2).abs().max()) <= 1e-6 * float(m2.abs().max()) + 1e-30, (key, step, i)
+                assert int(o1.state[a]["step"]) == int(o2.state[b]["step"])
+        sd1, sd2 = o1.state_dict(), o2.state_dict()
+        assert sd1["state"].keys() == sd2["state"].keys()
+        assert all(set(sd1["state"][k]) == {"step", "exp_avg", "exp_avg_sq"} for k in sd1["state"])
+    # Adam's first update moves every entry with a gradient above eps by lr, whatever the gradient's size
+    p = torch.nn.Parameter(torch.zeros(1000, device="cuda"))
+    o = HipAdam([p], lr=1e-3)
+    p.grad = torch.full_like(p, 3e-5)
+    o.step()
+    assert torch.allclose(p.detach(), torch.full_like(p, -1e-3), rtol=1e-3, atol=0)

@@ -1,5 +1,5 @@
 """Per-stream kernel sequence of ONE training step from a rocprofv3 --kernel-trace CSV (start offset, duration, name),
-plus per-stream busy time.  Usage: python tools/step_timeline.py <kernel_trace.csv> [step_from_end=2] [--brief] [--marks-per-step N]
+plus per-stream busy time.  Usage: python tools/step_timeline.py <kernel_trace.csv> [step_from_end=2] [--brief] [--marks-per-step N] [--mark KERNEL]
 (N = 2 for losses whose forward and backward are the same kernel symbol: ListNet, evidential)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -10,7 +10,11 @@ for r in rows:
     n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, r.get("Stream_Id") or r.get("Queue_Id")))
 ev.sort()
-marks = [e[0] for e in ev if "listmle_fwd" in e[2] or "listnet_kernel" in e[2] or "ranknet_fwd" in e[2] or "evidential_kernel" in e[2]]
+if "--mark" in sys.argv:                                   # e.g. --mark ranking_metrics_kernel: one per validation step
+    key = sys.argv[sys.argv.index("--mark") + 1]
+    marks = [e[0] for e in ev if key in e[2]]
+else:
+    marks = [e[0] for e in ev if "listmle_fwd" in e[2] or "listnet_kernel" in e[2] or "ranknet_fwd" in e[2] or "evidential_kernel" in e[2]]
 if "--marks-per-step" in sys.argv:
     marks = marks[::int(sys.argv[sys.argv.index("--marks-per-step") + 1])]
 lo, hi = marks[-1 - back], marks[-back]
