@@ -13,18 +13,51 @@ H, M = 300, 138881
 SECONDS = float(os.environ.get("RR_PROBE_SECONDS", "3"))
 
 
+def _sysfs_sclk():
+    """Current shader clock from amdgpu's sysfs table (the starred line of pp_dpm_sclk), MHz."""
+    import glob
+    import re
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for ln in open(f):
+                if "*" in ln:
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", ln)
+                    if m:
+                        return float(m.group(1))
+        except OSError:
+            pass
+    return None
+
+
+_SMI_KEYS_SHOWN = False
+
+
 def smi():
-    """(watts, sclk MHz) from one rocm-smi call; None where the field is missing."""
+    """(watts, sclk MHz) from one rocm-smi call (+ sysfs for the clock); None where the field is missing.  Round 3 looked
+    for a key starting with 'sclk clock level' and found none on this image (sclk nan): any key that mentions sclk and a
+    value in MHz counts now, and the keys seen are printed once."""
+    global _SMI_KEYS_SHOWN
+    import re
+    w = mhz = None
     try:
         out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
         d = json.loads(out)
         card = d[sorted(d)[0]]
+        if not _SMI_KEYS_SHOWN:
+            _SMI_KEYS_SHOWN = True
+            print("rocm-smi fields:", {k: v for k, v in card.items() if "clk" in k.lower() or "ower" in k}, flush=True)
         w = next((float(v) for k, v in card.items() if "ower" in k and "(W)" in k), None)
-        clk = next((v for k, v in card.items() if k.startswith("sclk clock level")), None)
-        mhz = float(clk.split("(")[1].split("M")[0]) if clk and "(" in clk else None
-        return w, mhz
+        for k, v in card.items():
+            if "sclk" in k.lower():
+                m = re.search(r"(\d+(?:\.\d+)?)\s*[Mm][Hh]z", str(v))
+                if m:
+                    mhz = float(m.group(1))
+                    break
     except Exception:                                                     # noqa: BLE001
-        return None, None
+        pass
+    if mhz is None:
+        mhz = _sysfs_sclk()
+    return w, mhz
 
 
 def run(name, fn):
