@@ -160,6 +160,31 @@ def calculate_ndcg(model, gpu, batches: Iterable, NDCG_cut: float = 0.5, is_orde
     return float(m[9]), float(m[10]), total_order, None
 
 
+def calculate_mse(model, gpu, batches: Iterable, exchange=None) -> float:
+    """Reference calculate_mse (train/eval.py:558-609; the `save_metric='mse'` criterion of train_listwise.py:345-351):
+    switches the model to eval mode and returns the mean squared error between the first output column and the targets
+    of the LAST batch - the reference overwrites its `MSE` in every iteration of the loop and returns the final one (:607-609),
+    which is kept.  Data parallel: the last global batch's squared errors and count are summed over the ranks."""
+    from .loss import MSELoss
+    model.eval()
+    last = None
+    with torch.no_grad():
+        for r_batch, p_batch, scope, targets, add_features in batches:
+            last = (r_batch, p_batch, scope, targets, add_features)
+        dev = torch.device("cuda", torch.cuda.current_device() if gpu is None else gpu)
+        v = torch.zeros(2, dtype=torch.float64, device=dev)                 # [sum of squared errors, count]
+        if last is not None and len(last[2]) > 0:
+            out = model(last[0], last[1], gpu=gpu, add_features=last[4])
+            pred = out[:, 0] if out.dim() > 1 else out
+            t = torch.as_tensor(last[3], dtype=torch.float32).reshape(-1)
+            n = int(pred.shape[0])
+            v[0] = MSELoss()(pred.contiguous(), t).double().sum() * n      # rr_mse_fwd_f32: the mean over this shard
+            v[1] = n
+        if exchange is not None and exchange.on:
+            v = exchange.sum(v)
+    return float(v[0] / v[1].clamp(min=1.0))
+
+
 def ndcg_at_k(scores, scope, relevance, gpu: int = None) -> np.ndarray:
     """metrics.NDCG(k=10, 'exp2') of every query: `relevance` are the grades, ranked by `scores`."""
     stats, _ = ranking_stats(scores, scope, relevance, gpu)

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import loss as RL
-from .eval import ranking_metrics
+from .eval import calculate_mse, ranking_metrics
 from .utils import save_checkpoint
 
 NDCG_METRICS = ["NDCG@1", "NDCG@2", "NDCG@25%", "NDCG@all"]
@@ -155,7 +155,7 @@ def _train(model, scheduler, train_batches, val_batches, path_checkpoints, optim
     # model.dropout_seed (a test knob that pins ONE stream for every step) must stay unset here.
     if getattr(model, "dropout_seed", None) is not None:
         model.dropout_seed = None
-    score_old = [0.0, 0.0, 0.0] if save_metric == "all" else 0.0
+    score_old = [0.0, 0.0, 0.0] if save_metric == "all" else (float("inf") if save_metric == "mse" else 0.0)   # :54-59
     history = []
     say = logger.info if (logger is not None and ex.is_writer) else (lambda *_: None)
     dev = next(model.parameters()).device
@@ -210,12 +210,20 @@ def _train(model, scheduler, train_batches, val_batches, path_checkpoints, optim
             if v >= score_old:
                 score_old = v
                 keep(path_checkpoints)
+        elif save_metric == "mse":                          # :345-351 (calculate_mse: the LAST validation batch's error)
+            mse_val = calculate_mse(model, gpu, [(b["r"], b["p"], b["scope"], b["targets"], b.get("add")) for b in val_batches],
+                                    exchange=ex)
+            if mse_val <= score_old:
+                score_old = mse_val
+                keep(path_checkpoints)
         else:
             raise Exception("Unknown save metric")
         saved = saved and path_checkpoints is not None
         last_loss = float(ex.sum(loss.detach().sum().reshape(1).clone()))     # the reference logs the last step's loss (:353)
         rec = dict(epoch=epoch + 1, train_loss=last_loss, top1=float(top1), top1_in_pred_top25=float(top25),
                    pred_top25_in_targ_top25=float(recall25), ndcg=[float(x) for x in ndcg], checkpoint=saved)
+        if save_metric == "mse":
+            rec["mse"] = float(mse_val)
         history.append(rec)
         if epoch_hook is not None:
             epoch_hook(epoch, model, rec)

@@ -406,3 +406,35 @@ def test_first_optimizer_step_matches_the_oracle(kind, parity_log):
     parity_log(f"{kind}: loss err {abs(float(loss.sum()) - l64):.1e}; worst gradient tensor {worst[1]}: {worst[0]:.1e} of its max "
                f"(fp32 oracle on the same tensor: {worst[2]:.1e}); Adam step 1 (lr {lr:.1e}): update sign differs from the fp64 "
                f"oracle's on {n_mis_hip} of {n_entries} entries (fp32 oracle: {n_mis_32})")
+
+
+def test_save_metric_mse_uses_the_last_validation_batch_like_the_reference(tmp_path):
+    """train_listwise.py:345-351 + eval.py:558-609: `save_metric='mse'` checkpoints whenever calculate_mse does not get
+    worse, and calculate_mse returns the squared error of the LAST validation batch only (the reference overwrites it in
+    every loop iteration)."""
+    from reactranker_amd import eval as RE
+    cfg = _cfg(1, None)
+    shapes = O.model_shapes(64, 3, 3, 3, 1, 1, True)
+    w = synth.seeded_weights(shapes, 31)
+    hip_tr, _ = _data(7000, 2, 4, 6)
+    hip_va, _ = _data(7100, 2, 4, 6)
+    model, opt, sch = _hip_side(cfg, w)
+    path = str(tmp_path / "ck" / "mse.pt")
+    seen = []
+
+    def hook(e, m, rec):
+        was = m.training
+        m.eval()
+        with torch.no_grad():
+            b = hip_va[-1]
+            o = m(b["r"], b["p"], gpu=0, add_features=b["add"]).double().cpu()
+        m.train(was)
+        seen.append(float(((o - b["targets"].double()) ** 2).mean()))
+    hist = TL.train(model, sch, hip_tr, hip_va, path, opt, 3, seed=5, gpu=0, task_type="regression", save_metric="mse", epoch_hook=hook)
+    assert all(abs(h["mse"] - s) <= 1e-6 * (1 + s) for h, s in zip(hist, seen))
+    best, want = float("inf"), []
+    for h in hist:
+        want.append(h["mse"] <= best)
+        best = min(best, h["mse"])
+    assert [h["checkpoint"] for h in hist] == want and os.path.exists(path)
+    assert abs(RE.calculate_mse(model, 0, [(b["r"], b["p"], b["scope"], b["targets"], b["add"]) for b in hip_va]) - seen[-1]) <= 1e-6 * (1 + seen[-1])
