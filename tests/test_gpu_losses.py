@@ -254,3 +254,27 @@ def test_top_scores_third_value_is_not_ranking_metrics_third_value():
         stats, _ = RE.ranking_stats(torch.tensor(np.concatenate(sc)).cuda(), scope, np.concatenate(tg), 0, 0.25, cut)
         assert np.allclose(stats[:, 9].cpu().numpy(), want[2][:, 0], rtol=0, atol=1e-6)
         assert np.allclose(stats[:, 10].cpu().numpy(), want[2][:, 1], rtol=1e-6, atol=1e-6)
+
+
+def test_ranking_metrics_at_the_longest_supported_list():
+    """One list of 8192 candidates (the kernels' kMaxLen: 128 KB of LDS for the metrics kernel's two f32 and four 16-bit
+    arrays) next to short ones, against the oracle's three evaluation loops; 8193 is refused with a status, not a fault."""
+    from reactranker_amd import eval as RE
+    rng = np.random.default_rng(21)
+    scope = [8192, 3, 64]
+    sc = [np.round(rng.standard_normal(c), 2).astype(np.float32) for c in scope]          # rounded: thousands of ties
+    tg = [rng.standard_normal(c).astype(np.float32) for c in scope]
+    s, t = torch.tensor(np.concatenate(sc)).cuda(), np.concatenate(tg)
+    r_top1, r_rec, r_top25, r_nd, r_orders = O.ranking_metrics_from_scores(sc, tg)
+    top1, rec, top25, nd = RE.ranking_metrics_from_scores(s, scope, t, 0)
+    assert (top1, top25) == (r_top1, r_top25) and abs(rec - r_rec) < 1e-12 and np.allclose(nd, r_nd, rtol=1e-10, atol=1e-12)
+    stats, order = RE.ranking_stats(s, scope, t, 0, 0.25, 0.5)
+    assert np.array_equal(order.cpu().numpy(), np.concatenate(r_orders).astype(np.int32))
+    a, b, c, _ = O.top_scores_from_scores(sc, tg, 0.25)
+    got = RE.top_scores_from_scores(s, scope, t, 0, 0.25)
+    assert got[0] == a and abs(got[1] - b) < 1e-12 and got[2] == c
+    o_nd, o_kl, rows = O.calculate_ndcg_from_scores(sc, tg, 0.5)
+    assert np.allclose(stats[:, 9].cpu().numpy(), rows[:, 0], rtol=0, atol=1e-6)
+    assert np.allclose(stats[:, 10].cpu().numpy(), rows[:, 1], rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        RE.ranking_stats(torch.zeros(8193, device="cuda"), [8193], np.zeros(8193, np.float32), 0)
