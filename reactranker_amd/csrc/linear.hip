@@ -47,6 +47,7 @@ struct LinearParams {
   int flags;
   uint32_t drop_thr;
   float keep_scale;
+  int persist;          // linear_split_kernel: one workgroup per CU walks row blocks blockIdx.x, + gridDim.x, ... (see there)
 };
 
 __device__ __forceinline__ int swz(int row, int kq) { return kq ^ ((0 - (row >> 2)) & 3); }
@@ -646,6 +647,9 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackMany P) {
 // are pre-split by rr_pack_weights (w_packed = 2) into the exact LDS image of a k-step (per column tile and term:
 // 64 lanes x 16 B, lane-linear) and stream L2 -> LDS by LDS-DMA, double buffered (2 x 57 KB: one workgroup per CU).
 // N > 304 (H = 600): two column blocks of 19 tiles (blockIdx.y), each streaming its own tiles of the image.
+#ifndef RR_EPI_MODE
+#define RR_EPI_MODE 1
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -692,6 +696,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   constexpr int CS_OFF = RS_EPI ? (WAVES * REGION > 2 * PANEL ? WAVES * REGION : 2 * PANEL) : 0;
   constexpr int BIAS_OFF = RS_EPI ? CS_OFF + WAVES * BN * 4 : 2 * PANEL;
   float* const bias_s = reinterpret_cast<float*>(smem + BIAS_OFF);
+  constexpr int PF_OFF = BIAS_OFF + BN * 4;            // persistent form: 2 KiB per wave for the next block's step-0 operand chunks
   const int t0 = blockIdx.y * NT;                      // first column tile of this workgroup
   const int nth = NTP - t0 < NT ? NTP - t0 : NT;       // its column tiles (the last workgroup of a row block may have fewer)
   const bool full = nth == NT;
@@ -717,10 +722,21 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     for (int i = 0; i < ph * RR_SPLIT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
   }
 #endif
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * S_BM;
-  const int64_t m = m0 + wave * 16 + fr;
-  const bool row_ok = m < a.M;
-  const int64_t mc = row_ok ? m : a.M - 1;
+  // Persistent form (plain-operand GEMMs of the 12-wave geometry, chosen by the host: P.persist): gridDim.x = one workgroup
+  // per CU, each walking the row blocks blockIdx.x, blockIdx.x + gridDim.x, ...  The k-loop's software pipeline (operand
+  // chunks two steps ahead, weight image one step ahead) simply continues across the block boundary: the last two steps of
+  // a block issue the NEXT block's first operand loads and its first weight image (the weights do not depend on the rows),
+  // so a block's ~5 us of dependent loads before its first MFMA - index, row pointer, first chunks, first image - run
+  // under the previous block's last MFMA blocks, and the store epilogue of block i is followed at once by MFMAs of block
+  // i+1 instead of by a new workgroup's prologue.  Same values, same order per element: bit-identical to the one-block form.
+  constexpr bool CAN_PERSIST = MODE == 0 && WAVES == 12 && NT == NTP && EPI == 0;
+  const bool persist = CAN_PERSIST && P.persist != 0;
+  const int64_t nblk = (a.M + S_BM - 1) / S_BM;
+  int64_t blk = blockIdx.x;
+  int64_t m0 = blk * S_BM;
+  int64_t m = m0 + wave * 16 + fr;
+  bool row_ok = m < a.M;
+  int64_t mc = row_ok ? m : a.M - 1;
   const float* const dummy = a.w;                      // any valid, 16-byte aligned GLOBAL address (keeps the loads global_load)
   const float* rowp1 = nullptr;
   const float* rowp2 = nullptr;
@@ -781,18 +797,42 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // segment (plus one step of slack for the prefetch) must fit inside that array
   static_assert(RR_ZERO_ROW % SK == 0 && RR_ZERO_ROW >= 2 * SK, "rr_zero_row must hold whole k-steps");
   const bool fastx_ok = FASTX && a.k1 + SK <= RR_ZERO_ROW && a.k2 + SK <= RR_ZERO_ROW;
-  const float* const xb1 = (rowp1 != nullptr ? rowp1 : rr_zero_row) + fkq * 8;
-  const float* const xb2 = (rowp2 != nullptr ? rowp2 : rr_zero_row) + fkq * 8;
+  const float* xb1 = (rowp1 != nullptr ? rowp1 : rr_zero_row) + fkq * 8;
+  const float* xb2 = (rowp2 != nullptr ? rowp2 : rr_zero_row) + fkq * 8;
   const float* const sb1 = (subp != nullptr ? subp : rr_zero_row) + fkq * 8;
+  const float* xb1n = xb1;                             // persistent form: the NEXT row block's operand rows
+  const float* xb2n = xb2;
+  bool has_next = false, wrapped = false;              // wrapped: this block was entered from the previous block's pipeline
+  auto next_rows = [&](int64_t nb) {                   // MODE 0 only: plain or index-gathered segment 1, plain segment 2
+    const int64_t mm = nb * S_BM + wave * 16 + fr;
+    const bool ok = mm < a.M;
+    const int64_t mmc = ok ? mm : a.M - 1;
+    const bool g1 = a.k1 > 0 && a.a1_idx != nullptr;
+    const int32_t j1 = g1 ? ldgi(a.a1_idx + mmc) : 0;
+    const float* r1 = nullptr;
+    const float* r2 = nullptr;
+    if (ok) {
+      if (a.k1 > 0) {
+        if (g1) {
+          if (j1 >= 0) r1 = a.a1 + static_cast<int64_t>(j1) * a.lda1;
+        } else {
+          r1 = a.a1 + mm * a.lda1;
+        }
+      }
+      if (a.k2 > 0) r2 = a.a2 + mm * a.lda2;
+    }
+    xb1n = (r1 != nullptr ? r1 : rr_zero_row) + fkq * 8;
+    xb2n = (r2 != nullptr ? r2 : rr_zero_row) + fkq * 8;
+  };
   auto interior = [&](int s) -> bool {                 // (wave-uniform)
     if (!fastx_ok) return false;
     return s < P.t1 ? (s + 1) * SK <= a.k1 : (s - P.t1 + 1) * SK <= a.k2;
   };
-  auto issue_x = [&](int s, int slot) {                // pure loads (unconditional, from a selected address)
+  auto issue_x = [&](int s, int slot, bool nextblk = false) {   // pure loads (unconditional, from a selected address)
     if (FASTX && fastx_ok) {
       const bool s1 = s < P.t1;
       const int off = (s1 ? s : s - P.t1) * SK;          // wave-uniform
-      const float* p = (s1 ? xb1 : xb2) + off;
+      const float* p = (s1 ? (nextblk ? xb1n : xb1) : (nextblk ? xb2n : xb2)) + off;
       const float* q = (MODE == 1 && s1) ? sb1 + off : rr_zero_row;   // (segment 2 has no subtract source: zeros, the count of loads per step stays NX)
       if (interior(s)) {
         ra[slot][0] = ldg4(p);
@@ -958,17 +998,37 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #else
   const bool late = DEEP && uwave >= WAVES / 2;
 #endif
+  // persistent form: step 0 of the NEXT row block, fetched by LDS-DMA into this wave's 2 KiB (lane-linear 16-byte slots:
+  // chunk pair A | B) - no register crosses the store epilogue for it.  Same addresses as issue_x(0, .) would read.
+  auto prefetch_next0 = [&]() {
+    const bool s1 = 0 < P.t1;
+    const float* p = s1 ? xb1n : xb2n;
+    const uint32_t dst = lds0 + PF_OFF + uwave * 2048;
+    if (interior(0)) {
+      rr_glds16(p, dst);
+      rr_glds16(p + 4, dst + 1024);
+    } else {
+      const int kl = fkq * 8, ks = s1 ? a.k1 : a.k2;
+      rr_glds16(kl < ks ? p : rr_zero_row, dst);
+      rr_glds16(kl + 4 < ks ? p + 4 : rr_zero_row, dst + 1024);
+    }
+  };
   auto step = [&](int s, int slot) {
     const bool more = s + 1 < nk, more2 = s + 2 < nk;
-    if (late) fixup(s, DEEP ? slot : 0);
+    const bool wrap = CAN_PERSIST && has_next;         // (uniform) the pipeline runs on into the next row block; nk is even
+    // (step 0 of a block entered through the wrap below finds its operand already split by EVERY wave: one register
+    // set - x0..x2 - crosses the store epilogue instead of two)
+    if (late && !(CAN_PERSIST && s == 0 && wrapped)) fixup(s, DEEP ? slot : 0);
     if (more) issue_w(s + 1);
+    else if (wrap) issue_w(0);                         // next block's first image: buffer 0, last read in step nk - 2
     if (DEEP) {
       if (more2) issue_x(s + 2, slot);
+      else if (wrap && more) prefetch_next0();         // s = nk - 2: the next block's step-0 chunks go to LDS, not to registers
     } else {
       if (more) issue_x(s + 1, 0);
     }
     mfma_block(s);
-    if (DEEP && more2) {
+    if (DEEP && (more2 || (wrap && more))) {           // (the two prefetch DMAs stand in for an issue_x: same count)
       if (NX == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else if (NX == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -991,6 +1051,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   __syncthreads();
   RR_STAMP(1);
 
+  for (;;) {                                            // one pass per row block (a single pass unless persistent)
+  if (CAN_PERSIST) {
+    has_next = persist && blk + gridDim.x < nblk;
+    if (has_next) next_rows(blk + gridDim.x);          // index -> row pointer now, first use two steps before the block ends
+  }
   for (int s = 0; s < nk; s += 2) {
     step(s, 0);
     if (s + 1 < nk) step(s + 1, 1);
@@ -1146,9 +1211,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     }
   }
   if (!done) {
-    const bool res_ok = rrow != nullptr;
+    // (with RR_EPI_MODE 1 the 12-wave forward forms that carry a residual take the row-contiguous epilogue above: this
+    // instantiation then never sees one, and its register ring is not needed)
+    constexpr bool MAY_RES = !(RR_EPI_MODE == 1 && WAVES == 12 && (MODE == 0 || MODE == 1) && EPI == 0);
+    const bool res_ok = MAY_RES && rrow != nullptr;
     const float* rbase = res_ok ? rrow : dummy;
-    constexpr int D = 4;
+    constexpr int D = MAY_RES ? 4 : 0;
     f32x4 ring[D + 1];
     auto ldres = [&](int tc) {
       const int n = n0 + tc * 16 + nq;
@@ -1165,10 +1233,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       const f32x4 vb = v + b;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = has_bias ? vb[e] : v[e];
-      const f32x4 vr = v + ring[tc % (D + 1)];
+      if (MAY_RES) {
+        const f32x4 vr = v + ring[tc % (D + 1)];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = res_ok ? vr[e] : v[e];
-      if (tc + D < NT) ring[(tc + D) % (D + 1)] = ldres(tc + D);
+        for (int e = 0; e < 4; ++e) v[e] = res_ok ? vr[e] : v[e];
+        if (tc + D < NT) ring[(tc + D) % (D + 1)] = ldres(tc + D);
+      }
       if (prow != nullptr && row_ok && n < a.N) *reinterpret_cast<f32x4*>(prow + n) = v;
       const f32x4 stored = finish(v, n);
       if (mb_on) {
@@ -1213,8 +1283,30 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       const f32x4 s01 = ld4(base) + ld4(base + BN);
       const f32x4 s23 = ld4(base + 2 * BN) + ld4(base + 3 * BN);
       if (n < a.N && m0 + h * 64 < a.M)
-        *reinterpret_cast<f32x4*>(a.colsum_partial + (static_cast<int64_t>(blockIdx.x) * (WAVES / 4) + h) * a.ld_partial + n) = s01 + s23;
+        *reinterpret_cast<f32x4*>(a.colsum_partial + (blk * (WAVES / 4) + h) * a.ld_partial + n) = s01 + s23;
     }
+  }
+  if (!(CAN_PERSIST && has_next)) break;
+  // next row block: its step-0 operand is split (early waves) or loaded (late waves), its step-1 chunks are in flight, its
+  // first weight image is in LDS buffer 0 - the state the prologue leaves behind
+  if (cs_on) __syncthreads();                          // the column-sum staging of this block has been read
+  wrapped = true;
+  blk += gridDim.x;
+  m0 = blk * S_BM;
+  m = m0 + wave * 16 + fr;
+  row_ok = m < a.M;
+  mc = row_ok ? m : a.M - 1;
+  xb1 = xb1n;
+  xb2 = xb2n;
+  if (nk > 1) issue_x(1, 1);                           // step 1: one MFMA block to land instead of two
+  {
+    const unsigned char* pf = smem + PF_OFF + uwave * 2048 + lane * 16;
+    ra[0][0] = *reinterpret_cast<const f32x4*>(pf);
+    ra[0][1] = *reinterpret_cast<const f32x4*>(pf + 1024);
+  }
+  fixup(0, 0);                                         // every wave (step 0 of a wrapped block skips the late split)
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4(0.f);
   }
 #ifdef RR_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2085,9 +2177,6 @@ __global__ void __launch_bounds__(256) linear_rowdot_kernel(const float* __restr
 }
 
 
-#ifndef RR_EPI_MODE
-#define RR_EPI_MODE 1
-#endif
 // RR_EPI_MODE (A/B knob): 0 = accumulator-layout epilogue everywhere, 1 = row-contiguous where the epilogue READS (a
 // residual), 2 = row-contiguous everywhere it applies.  Measured (profiles/r03_experiments.txt): with a residual read
 // 223 -> 196 us per isolated 139k-row launch; store-only epilogues do not gain and pay the LDS round trip; inside a
@@ -2097,7 +2186,9 @@ int launch_split_epi(const LinearParams& P, hipStream_t s) {
   // k-loop: two weight images + the bias slice; the 12-wave geometry's epilogue needs 12 transposition regions of
   // 8 x 77 float4, the column-sum / sign-bit staging and the bias slice (linear_split_kernel, "LDS layout")
   constexpr int panel2 = 2 * NT * 3 * 1024, bn4 = 16 * NT * 4;
-  constexpr int smem = WAVES == 12 ? ((12 * 8 * 77 * 16 > panel2 ? 12 * 8 * 77 * 16 : panel2) + 13 * bn4) : panel2 + bn4;
+  constexpr bool can_persist = MODE == 0 && WAVES == 12 && NT == NTP && EPI == 0;
+  constexpr int smem = (WAVES == 12 ? ((12 * 8 * 77 * 16 > panel2 ? 12 * 8 * 77 * 16 : panel2) + 13 * bn4) : panel2 + bn4) +
+                       (can_persist ? WAVES * 2048 : 0);       // + the persistent form's operand prefetch slots
   // > 64 KiB of LDS has to be asked for once per kernel AND per device (the attribute lives with the device's code
   // object); atomics because two host threads may launch the same instantiation at once (setting it twice is harmless)
   static std::atomic<uint64_t> configured{0};          // bit d: done on device d (devices >= 64 set it every launch)
@@ -2109,7 +2200,28 @@ int launch_split_epi(const LinearParams& P, hipStream_t s) {
       return RR_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) configured.fetch_or(uint64_t(1) << dev, std::memory_order_release);
   }
-  const dim3 grid(static_cast<unsigned>((P.a.M + 16 * WAVES - 1) / (16 * WAVES)), static_cast<unsigned>((NTP + NT - 1) / NT));
+  const int64_t nblk = (P.a.M + 16 * WAVES - 1) / (16 * WAVES);
+  // Persistent form (see the kernel): plain-operand GEMMs of the one-workgroup-per-CU geometry with more row blocks than
+  // CUs, an even number of k-steps (the pipeline's two slots / two image buffers keep their parity across the block
+  // boundary) and interior steps on the lean loader.  RR_NO_PERSIST (A/B knob) keeps one workgroup per row block.
+  if (MODE == 0 && WAVES == 12 && NT == NTP && EPI == 0) {
+    static int n_cu[64] = {0};
+    int cus = (dev >= 0 && dev < 64) ? n_cu[dev] : 0;
+    if (cus == 0) {
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1 << 30;
+      if (dev >= 0 && dev < 64) n_cu[dev] = cus;
+    }
+    const int nk = P.t1 + P.t2;
+    const bool lean = P.a.k1 + SK <= RR_ZERO_ROW && P.a.k2 + SK <= RR_ZERO_ROW;
+    if (nblk > cus && nk >= 2 && nk % 2 == 0 && lean && !getenv("RR_NO_PERSIST")) {
+      LinearParams Q = P;
+      Q.persist = 1;
+      const dim3 grid(static_cast<unsigned>(cus), 1);
+      linear_split_kernel<NTP, NT, MODE, WAVES, EPI><<<grid, 64 * WAVES, smem, s>>>(Q);
+      return rr_launch_status();
+    }
+  }
+  const dim3 grid(static_cast<unsigned>(nblk), static_cast<unsigned>((NTP + NT - 1) / NT));
   linear_split_kernel<NTP, NT, MODE, WAVES, EPI><<<grid, 64 * WAVES, smem, s>>>(P);
   return rr_launch_status();
 }
@@ -2165,6 +2277,7 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   P.t1 = (a.k1 + BK - 1) / BK;
   P.t2 = (a.k2 + BK - 1) / BK;
   P.flags = 0;
+  P.persist = 0;
   if (a.k1 > 0 && vec_ok(a.a1, a.lda1)) P.flags |= F_A1_VEC;
   if (a.k2 > 0 && vec_ok(a.a2, a.lda2)) P.flags |= F_A2_VEC;
   if (a.a1_sub && vec_ok(a.a1_sub, a.lda1_sub)) P.flags |= F_SUB_VEC;

@@ -17,6 +17,7 @@ from reactranker_amd import loss as RL
 from reactranker_amd._lib import lib
 from oracle import ref_cpu as O
 from tests.test_gpu_model import _masks_for, close, make_model
+from tests import helpers as Hh
 from tests.test_gpu_split import _compare
 
 pytestmark = pytest.mark.gpu
@@ -284,3 +285,52 @@ def test_split_path_nonfinite_and_huge_operands_behave_as_documented():
     den = x[clean].double().abs() @ W.double().abs().t() + 1e-300
     assert float(((osp[clean].double() - ref).abs() / den).max()) < 2e-6
     assert float(((osp[14].double() - x[14].double() @ W.double().t()).abs() / (x[14].double().abs() @ W.double().abs().t())).max()) < 2e-6
+
+
+@pytest.mark.parametrize("M", [49153, 71425, 138881])
+def test_persistent_split_gemm_is_bit_identical_to_one_block_per_workgroup(M):
+    """linear_split_kernel<19,19,0,12,0> runs persistent when there are more 192-row blocks than CUs (one workgroup per CU
+    walks blocks b, b + #CUs, ...; the k-loop's operand / weight pipeline continues across the block boundary, the next
+    block's step-0 chunks travel through LDS).  Same products in the same order per element: every output - C, the second
+    pre-activation output, the sign bits, the weighted column-sum partials - must equal the one-block-per-workgroup launch
+    (RR_NO_PERSIST) bit for bit, for the plain dX form, a forward form with bias / ReLU / dropout / side outputs, and the
+    two-segment operand of W_o; and stay within the f64 bounds of the other geometry tests."""
+    import os
+    torch.manual_seed(M)
+    dev, H = "cuda", 300
+    W = torch.randn(H, H, device=dev) / 17
+    b = torch.randn(H, device=dev)
+    x = torch.randn(M, H, device=dev)
+    cw = torch.rand(M, device=dev)
+    rowb = int(lib().rr_mask_bits_row_bytes(H))
+    Wo = torch.randn(H, 61 + H, device=dev) / 19
+    fa = torch.randn(M, 64, device=dev)[:, :61]
+
+    def run():
+        L = Fn.LinW(W, b)
+        out = {}
+        o, p = Fn.linear(M, H, L.pk_t(0, H), w_packed=True, a1=x, k1=H, colsum_w=cw)               # dX: plain + column sums
+        out["dx"], out["dx_colsum"] = o, p
+        bits = torch.zeros(M, rowb, dtype=torch.uint8, device=dev)
+        pre = torch.empty(M, H, device=dev)
+        out["fwd"] = Fn.linear(M, H, L.pk(H), w_packed=True, a1=x, k1=H, bias=b, act=Fn.ACT_RELU, drop_p=0.1, seed=9,
+                               c_pre=pre, mask_bits_out=bits)
+        out["fwd_pre"], out["fwd_bits"] = pre, bits
+        Lo = Fn.LinW(Wo, b)
+        out["wo"] = Fn.linear(M, H, Lo.pk(61, H), w_packed=True, a1=fa, k1=61, a2=x, k2=H, bias=b, act=Fn.ACT_RELU)   # 2 + 10 k-steps
+        torch.cuda.synchronize()
+        return out
+    assert "RR_NO_PERSIST" not in os.environ
+    got = run()
+    os.environ["RR_NO_PERSIST"] = "1"
+    try:
+        ref = run()
+    finally:
+        del os.environ["RR_NO_PERSIST"]
+    for k in got:
+        assert torch.equal(got[k], ref[k]), k
+    r64 = x.double() @ W.double()
+    den = x.double().abs() @ W.double().abs() + 1e-300
+    err = float(((got["dx"].double() - r64).abs() / den).max())
+    Hh.record(f"persistent dX GEMM M={M}: max err / sum|ab|", err, 2e-6)
+    assert err <= 2e-6
