@@ -1001,6 +1001,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // persistent form: step 0 of the NEXT row block, fetched by LDS-DMA into this wave's 2 KiB (lane-linear 16-byte slots:
   // chunk pair A | B) - no register crosses the store epilogue for it.  Same addresses as issue_x(0, .) would read.
   auto prefetch_next0 = [&]() {
+    next_rows(blk + gridDim.x);                        // (recomputed here and at the block switch: not live across the k-loop)
     const bool s1 = 0 < P.t1;
     const float* p = s1 ? xb1n : xb2n;
     const uint32_t dst = lds0 + PF_OFF + uwave * 2048;
@@ -1054,7 +1055,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   for (;;) {                                            // one pass per row block (a single pass unless persistent)
   if (CAN_PERSIST) {
     has_next = persist && blk + gridDim.x < nblk;
-    if (has_next) next_rows(blk + gridDim.x);          // index -> row pointer now, first use two steps before the block ends
   }
   for (int s = 0; s < nk; s += 2) {
     step(s, 0);
@@ -1063,6 +1063,20 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   RR_STAMP(2);
 
   // ---- epilogue: the accumulator layout is that of linear_fast_kernel (a lane holds 4 consecutive columns of one row)
+  // (persistent form: the lane id goes through an opaque asm per row block, so the epilogue's lane-derived offsets and
+  // addresses are recomputed here - a few VALU instructions - instead of being hoisted out of the block loop, kept live
+  // across the k-loop and spilled: 70 spilled registers / +60 MB of scratch writes per launch without this)
+  int lane_o = threadIdx.x;
+#ifndef RR_PERSIST_HOIST
+  if (CAN_PERSIST) asm volatile("" : "+v"(lane_o));
+#endif
+  const int tid = lane_o, lane = lane_o & 63, wave = lane_o >> 6;
+  const int fr = lane & 15, fkq = lane >> 4;
+  // this block's rows, from the (uniform) block index: nothing row-specific is carried through the k-loop in registers
+  const int64_t m0 = blk * S_BM;
+  const int64_t m = m0 + wave * 16 + fr;
+  const bool row_ok = m < a.M;
+  const int64_t mc = row_ok ? m : a.M - 1;
   const int nq = fkq * 4;
   float* crow = a.c + mc * a.ldc;
   const float* rrow = nullptr;
@@ -1292,10 +1306,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   if (cs_on) __syncthreads();                          // the column-sum staging of this block has been read
   wrapped = true;
   blk += gridDim.x;
-  m0 = blk * S_BM;
-  m = m0 + wave * 16 + fr;
-  row_ok = m < a.M;
-  mc = row_ok ? m : a.M - 1;
+  next_rows(blk);
   xb1 = xb1n;
   xb2 = xb2n;
   if (nk > 1) issue_x(1, 1);                           // step 1: one MFMA block to land instead of two
