@@ -641,20 +641,19 @@ def main():
             rd = SH.ShardSet(shard_paths)
             n = len(rd)
             log(f"streaming {n} distinct steps from {len(shard_paths)} shard file(s)")
-            # Two untimed steps through the streaming path first, like the warm-up of the resident region: the first
-            # streamed step allocates what a resident step never needs (the device-side f_bonds rebuild, a workspace for a
-            # step a few per cent larger than the pool's) - 37 ms on this run's box, ~95 ms on the round-3 driver box, which
-            # is ALL of the 0.925-0.975x the 200-step leg showed there (its per-step median was already below the resident
-            # region's).  A real epoch is 1563 steps: the first one is noise there, it was 8 % of a 200-step leg.
-            warm = SH.StepPrefetcher(rd, device, range(min(2, n)), depth=2)
-            warm.prime()
-            for wb in warm:
-                R.train_step(wb)
-            warm.close()
-            R.fence()
-            pf = SH.StepPrefetcher(rd, device, range(n), depth=3)
+            # Two untimed steps through the streaming pipeline first, like the warm-up of the resident region: the first
+            # streamed step pays for what a resident step never needs - the device-side f_bonds rebuild and the prefetcher's
+            # own staging buffers come out of the caching allocator (a fresh hipMalloc when its cached blocks have just been
+            # handed to the prefetcher), the reader thread makes its first HIP calls - 37 / 87 / ~95 ms on three boxes, which
+            # was ALL of the 0.925-0.975x the 200-step leg showed (its per-step median was already below the resident
+            # region's).  A real epoch is 1563 steps: its first step is noise there, it was 8 % of a 200-step leg.
+            n_warm = min(2, n)
+            pf = SH.StepPrefetcher(rd, device, list(range(n_warm)) + list(range(n)), depth=3)
             startup = pf.prime()                          # start-up latency of the pipeline, reported, not timed
             it = iter(pf)
+            for _ in range(n_warm):                       # the SAME pipeline: its buffers, its thread, its copy stream are
+                R.train_step(next(it))                    # in steady state when the timed epoch starts
+            R.fence()
             e_secs, e_per, _ = R.timed(lambda i: next(it), n)
             pf.close()
             te = torch.tensor([e_secs], dtype=torch.float64, device=device)

@@ -333,11 +333,20 @@ class StepPrefetcher:
             f.result()
 
     def prime(self) -> float:
-        """Block until the first step's H2D copy has been issued (the pipeline's start-up latency: first page-cache
-        touches, first use of the pinned slots); returns the seconds waited.  Optional - iteration works without it."""
+        """Block until the first step's H2D copy has been issued and completed (the pipeline's start-up latency: first
+        page-cache touches, first use of the pinned slots, first DMA out of them); returns the seconds waited.  Optional -
+        iteration works without it."""
         t0 = time.perf_counter()
         while self.ready.empty() and self._err is None and self.thread.is_alive():
             time.sleep(0.0005)
+        # ... and has LANDED: the first DMA out of freshly pinned slots can take tens of milliseconds (measured: 37-95 ms
+        # showing up in the first consumer step when only the issue was awaited)
+        try:
+            first = self.ready.queue[0]
+            if first is not None:
+                first[2].synchronize()
+        except IndexError:
+            pass
         return time.perf_counter() - t0
 
     def _views(self, slot: int, i: int) -> Dict[str, torch.Tensor]:
