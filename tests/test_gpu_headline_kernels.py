@@ -305,6 +305,8 @@ def test_persistent_split_gemm_is_bit_identical_to_one_block_per_workgroup(M):
     rowb = int(lib().rr_mask_bits_row_bytes(H))
     Wo = torch.randn(H, 61 + H, device=dev) / 19
     fa = torch.randn(M, 64, device=dev)[:, :61]
+    small = torch.randn(5000, H, device=dev)
+    gidx = torch.randint(-1, 5000, (M,), device=dev, dtype=torch.int32)
 
     def run():
         L = Fn.LinW(W, b)
@@ -318,6 +320,7 @@ def test_persistent_split_gemm_is_bit_identical_to_one_block_per_workgroup(M):
         out["fwd_pre"], out["fwd_bits"] = pre, bits
         Lo = Fn.LinW(Wo, b)
         out["wo"] = Fn.linear(M, H, Lo.pk(61, H), w_packed=True, a1=fa, k1=61, a2=x, k2=H, bias=b, act=Fn.ACT_RELU)   # 2 + 10 k-steps
+        out["gathered"] = Fn.linear(M, H, L.pk(H), w_packed=True, a1=small, k1=H, a1_idx=gidx, bias=b)   # rows through an index, -1 = no row
         torch.cuda.synchronize()
         return out
     assert "RR_NO_PERSIST" not in os.environ
@@ -334,3 +337,8 @@ def test_persistent_split_gemm_is_bit_identical_to_one_block_per_workgroup(M):
     err = float(((got["dx"].double() - r64).abs() / den).max())
     Hh.record(f"persistent dX GEMM M={M}: max err / sum|ab|", err, 2e-6)
     assert err <= 2e-6
+    z = torch.zeros(1, device=dev)
+    A = torch.where(gidx[:, None] >= 0, small[gidx.clamp(min=0).long()], z)
+    rg = A.double() @ W.double().t() + b.double()
+    dg = A.double().abs() @ W.double().abs().t() + b.double().abs() + 1e-300
+    assert float(((got["gathered"].double() - rg).abs() / dg).max()) <= 2e-6
