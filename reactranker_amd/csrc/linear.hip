@@ -723,19 +723,28 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   }
 #endif
   // Persistent form (plain-operand GEMMs of the 12-wave geometry, chosen by the host: P.persist): gridDim.x = one workgroup
-  // per CU, each walking the row blocks blockIdx.x, blockIdx.x + gridDim.x, ...  The k-loop's software pipeline (operand
-  // chunks two steps ahead, weight image one step ahead) simply continues across the block boundary: the last two steps of
-  // a block issue the NEXT block's first operand loads and its first weight image (the weights do not depend on the rows),
-  // so a block's ~5 us of dependent loads before its first MFMA - index, row pointer, first chunks, first image - run
-  // under the previous block's last MFMA blocks, and the store epilogue of block i is followed at once by MFMAs of block
-  // i+1 instead of by a new workgroup's prologue.  Same values, same order per element: bit-identical to the one-block form.
+  // per CU, each owning a CONTIGUOUS range of rows - an equal share of the 64-row units, so every CU finishes at the same
+  // time - and walking it in blocks of up to 12 waves x 16 rows; the last block of a range has 4 or 8 active waves (one or
+  // two per SIMD instead of three: it takes 1/3 or 2/3 of a full block's time, where the one-block-per-workgroup launch
+  // pays a whole second round for it).  The k-loop's software pipeline (operand chunks two steps ahead, weight image one
+  // step ahead) continues across the block boundary: the last step of a block issues the NEXT block's first weight image
+  // (the weights do not depend on the rows), the step before it fetches the next block's step-0 operand chunks, so a
+  // block's ~5 us of dependent loads before its first MFMA run under the previous block's last MFMA blocks.  Same values,
+  // same order per element: bit-identical to the one-block form.  Rows are counted in groups of 16 (one wave's rows).
   constexpr bool CAN_PERSIST = MODE == 0 && WAVES == 12 && NT == NTP && EPI == 0;
   const bool persist = CAN_PERSIST && P.persist != 0;
-  const int64_t nblk = (a.M + S_BM - 1) / S_BM;
-  int64_t blk = blockIdx.x;
-  int64_t m0 = blk * S_BM;
+  int64_t g_cur = static_cast<int64_t>(blockIdx.x) * WAVES;            // first 16-row group of the current block
+  int64_t g_end = g_cur + WAVES;                                        // end of this workgroup's range
+  if (persist) {
+    const int64_t units = (a.M + 63) / 64, G = gridDim.x;
+    const int64_t base = units / G, rem = units % G, p = blockIdx.x;
+    g_cur = 4 * (p * base + (p < rem ? p : rem));
+    g_end = g_cur + 4 * (base + (p < rem ? 1 : 0));
+  }
+  int nw = g_end - g_cur < WAVES ? static_cast<int>(g_end - g_cur) : WAVES;   // active waves of the current block (uniform)
+  int64_t m0 = g_cur * 16;
   int64_t m = m0 + wave * 16 + fr;
-  bool row_ok = m < a.M;
+  bool row_ok = wave < nw && m < a.M;
   int64_t mc = row_ok ? m : a.M - 1;
   const float* const dummy = a.w;                      // any valid, 16-byte aligned GLOBAL address (keeps the loads global_load)
   const float* rowp1 = nullptr;
@@ -803,9 +812,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   const float* xb1n = xb1;                             // persistent form: the NEXT row block's operand rows
   const float* xb2n = xb2;
   bool has_next = false, wrapped = false;              // wrapped: this block was entered from the previous block's pipeline
-  auto next_rows = [&](int64_t nb) {                   // MODE 0 only: plain or index-gathered segment 1, plain segment 2
-    const int64_t mm = nb * S_BM + wave * 16 + fr;
-    const bool ok = mm < a.M;
+  auto next_rows = [&](int64_t g, int nwn) {           // MODE 0 only: plain or index-gathered segment 1, plain segment 2
+    const int64_t mm = (g + wave) * 16 + fr;
+    const bool ok = wave < nwn && mm < a.M;
     const int64_t mmc = ok ? mm : a.M - 1;
     const bool g1 = a.k1 > 0 && a.a1_idx != nullptr;
     const int32_t j1 = g1 ? ldgi(a.a1_idx + mmc) : 0;
@@ -887,6 +896,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     split_pair(v1.z, v1.w, t0, t1, t2); x0.w = t0; x1.w = t1; x2.w = t2;
   };
   auto fixup = [&](int s, int slot) {                  // first use of the loads: selects, mask / subtract, split
+    if (CAN_PERSIST && uwave >= nw) return;             // (its loads are still issued: every wave keeps the same vmcnt sequence)
     if (FASTX && fastx_ok) {
       f32x4 v0 = ra[slot][0], v1 = ra[slot][1];
       f32x4 u0 = f32x4(0.f), u1 = f32x4(0.f);
@@ -957,6 +967,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     }
   };
   auto mfma_block = [&](int s) {
+    if (CAN_PERSIST && uwave >= nw) return;             // (uniform) a wave without rows in a short last block: no MFMAs, no LDS reads
     const u32x4* Ws = reinterpret_cast<const u32x4*>(smem + (s & 1) * PANEL) + lane;
     const bf16x8 b0 = as_bf16x8(x0), b1 = as_bf16x8(x1), b2 = as_bf16x8(x2);
     // the three weight terms of tile j+1 are read while the six MFMAs of tile j run (pinned with sched_group_barrier:
@@ -1001,7 +1012,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // persistent form: step 0 of the NEXT row block, fetched by LDS-DMA into this wave's 2 KiB (lane-linear 16-byte slots:
   // chunk pair A | B) - no register crosses the store epilogue for it.  Same addresses as issue_x(0, .) would read.
   auto prefetch_next0 = [&]() {
-    next_rows(blk + gridDim.x);                        // (recomputed here and at the block switch: not live across the k-loop)
+    next_rows(g_cur + nw, g_end - (g_cur + nw) < WAVES ? static_cast<int>(g_end - (g_cur + nw)) : WAVES);   // (recomputed at the block switch: not live across the k-loop)
     const bool s1 = 0 < P.t1;
     const float* p = s1 ? xb1n : xb2n;
     const uint32_t dst = lds0 + PF_OFF + uwave * 2048;
@@ -1054,7 +1065,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 
   for (;;) {                                            // one pass per row block (a single pass unless persistent)
   if (CAN_PERSIST) {
-    has_next = persist && blk + gridDim.x < nblk;
+    has_next = persist && g_cur + nw < g_end;
   }
   for (int s = 0; s < nk; s += 2) {
     step(s, 0);
@@ -1073,9 +1084,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   const int tid = lane_o, lane = lane_o & 63, wave = lane_o >> 6;
   const int fr = lane & 15, fkq = lane >> 4;
   // this block's rows, from the (uniform) block index: nothing row-specific is carried through the k-loop in registers
-  const int64_t m0 = blk * S_BM;
+  const int64_t m0 = g_cur * 16;
   const int64_t m = m0 + wave * 16 + fr;
-  const bool row_ok = m < a.M;
+  const bool row_ok = wave < nw && m < a.M;
   const int64_t mc = row_ok ? m : a.M - 1;
   const int nq = fkq * 4;
   float* crow = a.c + mc * a.ldc;
@@ -1296,8 +1307,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       const float* base = cs_lds + h * 4 * BN + q * 4;
       const f32x4 s01 = ld4(base) + ld4(base + BN);
       const f32x4 s23 = ld4(base + 2 * BN) + ld4(base + 3 * BN);
-      if (n < a.N && m0 + h * 64 < a.M)
-        *reinterpret_cast<f32x4*>(a.colsum_partial + (blk * (WAVES / 4) + h) * a.ld_partial + n) = s01 + s23;
+      if (n < a.N && h * 4 < nw && m0 + h * 64 < a.M)    // (one partial row per 64-row unit; a short last block owns fewer)
+        *reinterpret_cast<f32x4*>(a.colsum_partial + (g_cur / 4 + h) * a.ld_partial + n) = s01 + s23;
     }
   }
   if (!(CAN_PERSIST && has_next)) break;
@@ -1305,8 +1316,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // first weight image is in LDS buffer 0 - the state the prologue leaves behind
   if (cs_on) __syncthreads();                          // the column-sum staging of this block has been read
   wrapped = true;
-  blk += gridDim.x;
-  next_rows(blk);
+  g_cur += nw;
+  nw = g_end - g_cur < WAVES ? static_cast<int>(g_end - g_cur) : WAVES;
+  next_rows(g_cur, nw);
   xb1 = xb1n;
   xb2 = xb2n;
   if (nk > 1) issue_x(1, 1);                           // step 1: one MFMA block to land instead of two
@@ -2227,6 +2239,7 @@ int launch_split_epi(const LinearParams& P, hipStream_t s) {
     if (nblk > cus && nk >= 2 && nk % 2 == 0 && lean && !getenv("RR_NO_PERSIST")) {
       LinearParams Q = P;
       Q.persist = 1;
+      // every CU an equal share of the 64-row units (the granularity of the column-sum partials)
       const dim3 grid(static_cast<unsigned>(cus), 1);
       linear_split_kernel<NTP, NT, MODE, WAVES, EPI><<<grid, 64 * WAVES, smem, s>>>(Q);
       return rr_launch_status();

@@ -438,3 +438,51 @@ def test_save_metric_mse_uses_the_last_validation_batch_like_the_reference(tmp_p
         best = min(best, h["mse"])
     assert [h["checkpoint"] for h in hist] == want and os.path.exists(path)
     assert abs(RE.calculate_mse(model, 0, [(b["r"], b["p"], b["scope"], b["targets"], b["add"]) for b in hip_va]) - seen[-1]) <= 1e-6 * (1 + seen[-1])
+
+
+def test_test_function_reports_evaluate_top_scores_and_calculate_ndcg(tmp_path):
+    """reactranker_amd.main.test (train/test_listwise.py:10-86): the checkpoint's scaler flips the sign of raw targets unless
+    'lgk', the triple is evaluate_top_scores at ratio 0.25, and with cal_ngcd the NDCG@0.25 / KL of calculate_ndcg on the
+    DE-STANDARDISED outputs plus its per-candidate listing - all against the oracle's restatements on the model's own scores."""
+    import logging
+    from reactranker_amd import main as RM
+    from reactranker_amd.utils import save_checkpoint
+    cfg = _cfg(1, None)
+    shapes = O.model_shapes(64, 3, 3, 3, 1, 1, True)
+    w = synth.seeded_weights(shapes, 41)
+    model = build_model(dropout=0.0, **cfg)
+    model.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    model = model.cuda()
+    path = str(tmp_path / "ck" / "0.pt")
+    mean, std = 1.7, 0.6
+    save_checkpoint(path, model, mean, std)
+    hip_te, _ = _data(8000, 2, 5, 9)
+    scores = _hip_val_scores(model, hip_te)
+    sq, tq = [], []
+    for s, b in zip(scores, hip_te):
+        off = 0
+        for n in b["scope"]:
+            sq.append(s[off:off + n])
+            tq.append(-b["targets"][off:off + n].double().numpy())          # target_name 'ea': sign flipped (:30-35)
+            off += n
+    a, bb, c, _ = O.top_scores_from_scores(sq, tq, 0.25)
+    m2 = build_model(dropout=0.0, **cfg)
+    got = RM.test(m2, hip_te, path, 0, logging.getLogger("t"), "ea", cal_ngcd=True, is_order=True, return_order=True)
+    assert got[0] == a and abs(got[1] - bb) < 1e-12 and got[2] == c
+    nd, kl, _ = O.calculate_ndcg_from_scores(sq, tq, 0.25, mean, std)
+    rows = np.asarray(got[3])
+    assert rows.shape == (sum(len(x) for x in sq), 4) and got[4] is None
+    # the listing: targets in descending order per query, predictions de-standardised (:379-388)
+    off = 0
+    for s, t in zip(sq, tq):
+        blk = rows[off:off + len(s)]
+        assert np.all(np.diff(blk[:, 0]) <= 0) and np.allclose(np.sort(blk[:, 1]), np.sort(s * std + mean), atol=1e-5)
+        off += len(s)
+    got2 = RM.test(m2, hip_te, path, 0, None, "lgk")                        # 'lgk': no sign flip (:33-34)
+    a2, b2, c2, _ = O.top_scores_from_scores(sq, [-t for t in tq], 0.25)
+    assert got2[0] == a2 and abs(got2[1] - b2) < 1e-12 and got2[2] == c2
+    # NDCG / KL through the logger-free path
+    from reactranker_amd.eval import calculate_ndcg
+    g_nd, g_kl, _, _ = calculate_ndcg(m2.cuda().eval(), 0, [(b["r"], b["p"], b["scope"], -b["targets"], b["add"]) for b in hip_te],
+                                      NDCG_cut=0.25, means=mean, stds=std)
+    assert abs(g_nd - nd) < 1e-6 and abs(g_kl - kl) < 1e-5 * max(1.0, abs(kl))
