@@ -224,6 +224,18 @@ class Exchange:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def check_same_steps(self, n_steps: int, device) -> None:
+        """Every rank must take the same number of optimizer steps (each is one all-reduce): a rank that is handed fewer
+        batches would leave the others waiting in the collective for ever.  Checked up front where the count is known."""
+        if not self.on:
+            return
+        v = torch.tensor([float(n_steps), -float(n_steps)], dtype=torch.float64, device=device)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+        lo, hi = -float(v[1]), float(v[0])
+        if lo != hi:
+            raise RuntimeError(f"data-parallel training: ranks hold different numbers of steps ({int(lo)} .. {int(hi)}); shard every "
+                               "global step over all ranks (reactranker_amd.dp.shard_query_batch), empty shards included")
+
     def broadcast_model(self, model: torch.nn.Module) -> None:
         """Identical replicas: rank 0's parameters and buffers everywhere (what DistributedDataParallel does at wrap time)."""
         if self.on:

@@ -59,6 +59,7 @@ def _run_train(model, scheduler, train_batches, val_batches, path_checkpoints, o
         tn = "lgk" if target_name == "lgk" else "ea"
         train_batches, val_batches, mean, std = standardize_batches(list(train_batches), list(val_batches), tn, True, None, ex)
     ex.broadcast_model(model)
+    ex.check_same_steps(len(train_batches), next(model.parameters()).device)
     score_old = [0.0, 0.0, 0.0] if save_metric == "all" else 0.0
     say = logger.info if (logger is not None and ex.is_writer) else (lambda *_: None)
     history = []

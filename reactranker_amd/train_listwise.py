@@ -150,6 +150,8 @@ def _train(model, scheduler, train_batches, val_batches, path_checkpoints, optim
         train_batches, val_batches, mean, std = standardize_batches(list(train_batches), list(val_batches), target_name,
                                                                      normalize_target, save_metric, ex)
     ex.broadcast_model(model)                         # identical replicas (a no-op for one process)
+    if not callable(train_batches):
+        ex.check_same_steps(len(train_batches), next(model.parameters()).device)
     # dropout streams: every forward draws a fresh stream seed from torch's generator (mpn._fresh_seed), which the
     # manual_seed above makes reproducible - like the reference, whose nn.Dropout advances that generator per call.
     # model.dropout_seed (a test knob that pins ONE stream for every step) must stay unset here.

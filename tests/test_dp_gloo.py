@@ -200,6 +200,12 @@ def _exchange_worker(rank, world, port, ret):
         w = [ex.weight(k, local, g2) for k in ("mle", "listnet", "ranknet", "evidential_ranking", "regression")]
         tot = ex.sum(torch.tensor(w, dtype=torch.float64))
         ok = ok and bool(torch.allclose(tot, torch.ones(5, dtype=torch.float64), atol=1e-12))     # the weights partition 1
+        ex.check_same_steps(7, "cpu")                                          # equal everywhere: passes
+        try:
+            ex.check_same_steps(7 + rank, "cpu")                               # one rank holds a step more: every rank raises
+            ok = False
+        except RuntimeError:
+            pass
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
