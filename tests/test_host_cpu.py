@@ -342,3 +342,25 @@ def test_molgraph_from_smiles_says_what_is_missing_without_rdkit():
         featurization.MolGraph("CCO")
     with pytest.raises(RuntimeError, match="RDKit"):
         featurization.mol2graph(["CCO", "CC"])
+
+
+def test_round4_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument checks run before any launch, so they can be exercised on the CPU: the ABI-revision-6 entry points return
+    RR_ERR_ARG (-1) for null pointers / out-of-range parameters instead of faulting."""
+    l = _lib.lib()
+    assert l.rr_adam_step_f32(None, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == -1          # null descriptor array
+    arr = (_lib.AdamTensor * 1)()
+    p = ctypes.cast(arr, ctypes.c_void_p)
+    assert l.rr_adam_step_f32(p, 1, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == -1             # step counts from 1
+    assert l.rr_adam_step_f32(p, 1, 1, 1e-3, 1.0, 0.999, 1e-8, 0.0, None) == -1             # beta1 < 1
+    assert l.rr_adam_step_f32(p, _lib.RR_MAX_ADAM + 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == -1
+    assert l.rr_adam_step_f32(p, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == 0              # a tensor without gradient: nothing to do
+    # rr_ranking_metrics_f32: ratio and cut are fractions
+    one = ctypes.c_void_p(16)
+    assert l.rr_ranking_metrics_f32(one, 1, one, one, 1, 4, 1.5, 0.5, one, one, None) == -1
+    assert l.rr_ranking_metrics_f32(one, 1, one, one, 1, 4, 0.25, -0.1, one, one, None) == -1
+    assert l.rr_ranking_metrics_f32(one, 1, one, one, 0, 4, 0.25, 0.5, one, one, None) == 0   # no queries: nothing launched
+    assert l.rr_ranking_metrics_f32(one, 1, one, one, 1, 8193, 0.25, 0.5, one, one, None) == -4   # RR_ERR_UNSUPPORTED: list too long
+    # rr_reaction_saved_f32: needs model / step / output slots
+    assert l.rr_reaction_saved_f32(None, None, 0, 0, 0, None, None, None) == -1
+    assert l.rr_comm_backend() in (0, 1, 2)
