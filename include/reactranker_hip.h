@@ -67,6 +67,11 @@ int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src,
                              const int32_t* idx, int64_t n_out, int K, int H,
                              const float* row0_partial, int64_t n_partial, int64_t ld_partial,
                              float* out, int64_t ld_out, rr_stream_t stream);
+/* Both of the above in one entry point (row0_partial may be NULL), plus an optional magnitude output:
+ * *amax_out = max(*amax_out, max |out|) - see rr_gather_epi.amax_out. */
+int rr_gather_sum_amax_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
+                           int H, const float* row0_partial, int64_t n_partial, int64_t ld_partial, float* out,
+                           int64_t ld_out, float* amax_out, rr_stream_t stream);
 
 /* out[r, 0:H] = sum_{j in [offsets[r], offsets[r+1])} src[idx[j], 0:H]   (CSR form, offsets has n_out+1 entries)
  * The adjoint of index_select_ND (utils.py:176-193) for a GENERIC index tensor: autograd's index_select
@@ -110,6 +115,8 @@ typedef struct rr_gather_epi {
   float mask_scale;
   int n_adds;               int64_t ld_add;      /* every addend is [n_out, ld_add] */
   const float* adds[RR_MAX_GATHER_ADDS];
+  float* amax_out;          /* optional: *amax_out = max(*amax_out, max |out|) (device float, atomically: zero it first) - the
+                               bound a two-f16-term GEMM needs of this result (rr_linear_args.a1_amax) without a pass over it */
 } rr_gather_epi;
 int rr_gather_sum_epi_f32(const float* src, int64_t n_src, int64_t ld_src,
                           const int32_t* idx, int64_t n_out, int K, int H,
@@ -178,7 +185,14 @@ typedef enum rr_act { RR_ACT_NONE = 0, RR_ACT_RELU = 1 } rr_act;
  * v_mfma_f32_16x16x32_bf16 - no operand bit is dropped, what is omitted lies below 2^-26 |x w| per product, and the
  * measured error against f64 is at or below the f32-MFMA kernel's.  Differences in kind on
  * that path: an infinite operand, or a finite |x| >= 3.3962e38, turns its output row into NaN (the f32 MFMA gives
- * +-inf).  Dropout keep-mask = rr_dropout_keep(seed, m*N + n).
+ * +-inf).  With w_packed = 3 each operand is scaled by a power of two S that puts its tensor's largest magnitude (the
+ * caller's a*_amax bounds; the weight's own, found by the packer) just below 2^15 and written as TWO f16 terms,
+ * S x = h + l, h = f16(S x), l = f16(S x - h) (round to nearest even; the remainder is exact): 22 significant bits of
+ * every element that is within 2^-18 of its tensor's largest, an absolute error below 2^-40 of that largest otherwise;
+ * the three products h h, h l, l h are accumulated in f32 by v_mfma_f32_16x16x32_f16 and the result is scaled back
+ * (exactly).  Omitted: l l, below 2^-22 |x w|.  Measured against f64 on N(0,1) operands, K = 300: mean error
+ * 2.6e-8 of sum |x||w| (three bf16 terms 1.6e-8, the f32 MFMA chain 2.0e-8), maximum below the f32 chain's
+ * (tools/f16_gemm_bench.py).  Dropout keep-mask = rr_dropout_keep(seed, m*N + n).
  * `residual` may alias `c` (in-place accumulate).  Vector loads need 16-byte aligned base
  * pointers and leading dimensions that are multiples of 4; otherwise a scalar path runs. */
 typedef struct rr_linear_args {
@@ -195,7 +209,9 @@ typedef struct rr_linear_args {
   const float* w;        int64_t ldw;               /* [N, k1+k2] row-major (nn.Linear.weight), or */
   int w_packed;                                     /* 1: the zero-padded layout of rr_pack_weight_f32;
                                                        2: the three-bf16-term images of rr_pack_weights_f32
-                                                          (rr_pack_desc.split): f32 result on the bf16 matrix core */
+                                                          (rr_pack_desc.split = 1): f32 result on the bf16 matrix core;
+                                                       3: its two-f16-term images (rr_pack_desc.split = 2): 22 significant
+                                                          bits per operand, half the matrix instructions (see below) */
   const float* bias;                                /* [N] or NULL */
   const float* residual; int64_t ldr;               /* [M, N] or NULL */
   const int32_t* residual_idx;                      /* optional: row m adds residual[residual_idx[m]] (shared `input`
@@ -219,8 +235,15 @@ typedef struct rr_linear_args {
                                                        per block of up to 304 columns 2 x 20 bytes - byte 20*h + t holds
                                                        columns 16*t + 8*h .. + 7 (bit e = column + e).  What a later
                                                        dX GEMM needs of this activation (a_mask > 0), at 1/32 of the bytes */
-  const uint8_t* a_mask_bits;                       /* alternative to a_mask (w_packed = 2, k2 = 0, k1 % 4 == 0): such a bit
+  const uint8_t* a_mask_bits;                       /* alternative to a_mask (w_packed >= 2, k2 = 0, k1 % 4 == 0): such a bit
                                                        image over the k1 columns of A; a_mask is then not read */
+  const float* a1_amax;                             /* w_packed = 3 only (required there for every operand present): DEVICE */
+  const float* a1_sub_amax;                         /* floats, each >= max |x| over the elements of a1 / a1_sub / a2 this call */
+  const float* a2_amax;                             /* can read (rr_amax_f32 computes one; a bound that is too large costs
+                                                       low-end precision, one that is too small overflows f16) */
+  float* c_amax_out;                                /* optional outputs (w_packed >= 2): *p = max(*p, max |C| stored) and the same */
+  float* dz_amax_out;                               /* for dz_out - the bound the NEXT GEMM needs of this one's result, without a
+                                                       pass over it (device floats, atomically maxed: zero them first) */
 } rr_linear_args;
 
 int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream);
@@ -247,7 +270,10 @@ typedef struct rr_pack_desc {
                         rows <= 608) receives every element of L as three bf16 terms t0 + t1 + t2 == L[r, c] EXACTLY
                         (t0 = bf16(x), t1 = bf16(x - t0), t2 = x - t0 - t1), laid out as the LDS image of each
                         32-deep k-step of rr_linear_f32's w_packed = 2 path:
-                        [k-step][16-column tile][term][lane 0..63][8 bf16], lane = (k-group of 8) * 16 + column */
+                        [k-step][16-column tile][term][lane 0..63][8 bf16], lane = (k-group of 8) * 16 + column.
+                        2: the same buffer receives TWO f16 terms of S * L[r, c] per element (same layout with two terms
+                        per tile), S = the power of two with 2^14 <= S * max |L| < 2^15, stored as one float right after
+                        the last k-step's image (rr_linear_f32, w_packed = 3, reads it there) */
 } rr_pack_desc;
 int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream);
 size_t rr_split_weight_bytes(int rows, int k1, int k2);
@@ -271,11 +297,20 @@ typedef struct rr_wgrad_args {
   void* workspace;       size_t workspace_bytes;
   int split;                                        /* 1: three-bf16-term operands on the bf16 matrix core (f32-equivalent
                                                        accuracy, see rr_pack_desc.split) where the geometry allows vector
-                                                       loads (16-byte aligned rows, N % 4 == 0); the f32 path otherwise */
+                                                       loads (16-byte aligned rows, N % 4 == 0); the f32 path otherwise.
+                                                       2: two-f16-term operands (rr_linear_args.w_packed = 3), which needs */
+  const float* dy_amax;                             /* ... DEVICE floats >= max |.| of dy, x1, x1_sub, x2 (as a1_amax above) */
+  const float* x1_amax;
+  const float* x1_sub_amax;
+  const float* x2_amax;
 } rr_wgrad_args;
 
 size_t rr_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream);
+
+/* *amax = max(*amax, max over the [rows, cols] block of |x[r * ld + c]|)   (device float, atomically: zero it first; NaN
+ * elements are skipped).  The operand bounds of the two-f16-term GEMMs (rr_linear_args.a1_amax, rr_wgrad_args.dy_amax). */
+int rr_amax_f32(const float* x, int64_t rows, int cols, int64_t ld, float* amax, rr_stream_t stream);
 
 /* ------------------------------------------------------------------ elementwise ---- */
 
@@ -516,10 +551,14 @@ enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2,
        RR_PLAN_F32_GEMM = 4,         /* encoder GEMMs on the f32 matrix core instead of the three-bf16-term path (w_packed = 2);
                                         forward and backward of a step must agree on it (it changes the workspace layout) */
        RR_PLAN_AUX_BACKWARD = 8,     /* reactant-encoder backward on the aux stream beside the product pass */
-       RR_PLAN_TRAIN = 16 };         /* a backward WILL follow: rr_reaction_forward also packs the transposed weights of the
+       RR_PLAN_TRAIN = 16,           /* a backward WILL follow: rr_reaction_forward also packs the transposed weights of the
                                         input-gradient GEMMs, in the same launch as the forward's packs, so the backward
                                         starts with its first GEMM instead of a pack.  Layout-changing like RR_PLAN_F32_GEMM:
                                         pass the same flags to both calls (ABI revision 6). */
+       RR_PLAN_F16X2_GEMM = 32 };    /* encoder GEMMs and weight gradients on two f16 terms per operand (w_packed = 3: half the
+                                        matrix instructions of the three-bf16-term path, 22 significant bits per operand); the
+                                        plan finds every operand's largest magnitude itself (rr_amax_f32, one slot per tensor
+                                        in the workspace).  Ignored with RR_PLAN_F32_GEMM; layout-changing (ABI revision 7). */
 
 typedef struct rr_step {
   rr_graph p, r, u;

@@ -38,6 +38,8 @@ class LinearArgs(C.Structure):
         ("c_pre", c_f32p), ("ld_pre", i64),
         ("colsum_w", c_f32p), ("colsum_partial", c_f32p), ("ld_partial", i64),
         ("mask_bits_out", C.c_void_p), ("a_mask_bits", C.c_void_p),
+        ("a1_amax", c_f32p), ("a1_sub_amax", c_f32p), ("a2_amax", c_f32p),
+        ("c_amax_out", c_f32p), ("dz_amax_out", c_f32p),
     ]
 
 
@@ -61,6 +63,7 @@ class WgradArgs(C.Structure):
         ("accumulate", i32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("split", i32),
+        ("dy_amax", c_f32p), ("x1_amax", c_f32p), ("x1_sub_amax", c_f32p), ("x2_amax", c_f32p),
     ]
 
 
@@ -71,13 +74,14 @@ class GatherEpi(C.Structure):
     _fields_ = [
         ("mask", c_f32p), ("ld_mask", i64), ("mask_bits", C.c_void_p), ("mask_scale", f32),
         ("n_adds", i32), ("ld_add", i64), ("adds", C.c_void_p * RR_MAX_GATHER_ADDS),
+        ("amax_out", c_f32p),
     ]
 
 
 RR_MAX_FFN = 8
 RR_G_FFN0 = 6
 RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
-RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM, RR_PLAN_AUX_BACKWARD, RR_PLAN_TRAIN = 1, 2, 4, 8, 16
+RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM, RR_PLAN_AUX_BACKWARD, RR_PLAN_TRAIN, RR_PLAN_F16X2_GEMM = 1, 2, 4, 8, 16, 32
 
 
 class Graph(C.Structure):
@@ -141,6 +145,7 @@ _SIGS = {
     "rr_linear_f32": (i32, [C.POINTER(LinearArgs), c_stream]),
     "rr_linear_colsum_rows": (i64, [i64]),
     "rr_gather_sum_padrow_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, c_f32p, i64, c_stream]),
+    "rr_gather_sum_amax_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, c_f32p, i64, c_f32p, c_stream]),
     "rr_packed_weight_ld": (i64, [i32, i32]),
     "rr_mask_bits_row_bytes": (i64, [i32]),
     "rr_split_weight_bytes": (C.c_size_t, [i32, i32, i32]),
@@ -148,6 +153,7 @@ _SIGS = {
     "rr_pack_weights_f32": (i32, [C.c_void_p, i32, c_stream]),
     "rr_linear_wgrad_workspace_bytes": (C.c_size_t, [i64, i32, i32]),
     "rr_linear_wgrad_f32": (i32, [C.POINTER(WgradArgs), c_stream]),
+    "rr_amax_f32": (i32, [c_f32p, i64, i32, i64, c_f32p, c_stream]),
     "rr_dropout_keep_host": (i32, [u64, u64, f32]),
     "rr_dropout_f32": (i32, [c_f32p, i64, f32, u64, c_f32p, c_stream]),
     "rr_relu_bwd_f32": (i32, [c_f32p, c_f32p, f32, c_f32p, c_f32p, i64, c_stream]),
@@ -205,7 +211,7 @@ class AdamTensor(C.Structure):
 
 
 RR_MAX_ADAM = 64
-ABI_VERSION = 6
+ABI_VERSION = 7
 (RR_SAVED_R_MSG, RR_SAVED_R_H, RR_SAVED_P_MSG, RR_SAVED_P_H, RR_SAVED_D_MSG, RR_SAVED_D_HID, RR_SAVED_VECS, RR_SAVED_FFN_H,
  RR_SAVED_R_MSG0_U, RR_SAVED_R_Z1_U) = range(10)
 

@@ -96,6 +96,26 @@ __device__ __forceinline__ void gather_walk(const float* __restrict__ src, int64
 }
 #endif
 
+// Largest stored magnitude of a launch, for the two-f16-term GEMM that reads the result (rr_linear_args.a1_amax): every
+// thread folds what it stores into a running maximum and the workgroup maxes it into a device float once - one atomic per
+// workgroup, and only while it can still raise the slot (a stale read costs an atomic, never a result).
+__device__ __forceinline__ float amax_fold(float m, f32x4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ float amax_fold(float m, float v) { return fmaxf(m, fabsf(v)); }
+__device__ inline void amax_commit(float m, float* out) {      // every thread of the workgroup calls it (out is uniform)
+  if (out == nullptr) return;
+  __shared__ float amax_part[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) amax_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(amax_part[0], amax_part[1]), fmaxf(amax_part[2], amax_part[3]));
+    if (m > *reinterpret_cast<volatile float*>(out)) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  }
+}
+
 // out[r] = sum_k (mask[j_k] > 0 ? src[j_k] * scale : 0): a ReLU / dropout backward (rr_relu_bwd_f32) folded into the gather
 // that consumes it - the same products in the same order, so the result equals the two-kernel sequence bit for bit, without
 // writing and re-reading the masked tensor.  Used where the masked tensor has no other reader: the shared-prefix reactant
@@ -189,9 +209,10 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
                                                          const int32_t* __restrict__ idx, int64_t n_out, int K,
                                                          int HV, float* __restrict__ out, int64_t ld_out,
                                                          const float* __restrict__ row0_partial, int64_t n_partial,
-                                                         int64_t ld_partial) {
+                                                         int64_t ld_partial, float* __restrict__ amax_out) {
   using V = typename Vec<VEC>::T;
   const int64_t total = n_out * HV;
+  float am = 0.f;
   // With a padding-row reduction the LAST HV blocks of the grid do that instead of gathering: block j sums column
   // group j of all partial rows (256 threads stride over the rows, then a fixed-order LDS + shuffle tree) and writes
   // out[0, group j] - the reduction runs next to the gather instead of as a straggler thread or an extra launch.
@@ -216,8 +237,12 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
       } else {
         v = rr_wave_sum(v);
       }
-      if (threadIdx.x == 0) st<VEC>(out + c, v);
+      if (threadIdx.x == 0) {
+        st<VEC>(out + c, v);
+        am = amax_fold(am, v);
+      }
     }
+    amax_commit(am, amax_out);
     return;
   }
 #ifdef RR_GATHER_WALK
@@ -228,12 +253,16 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
       const bool skip0 = row0_partial != nullptr;
       auto pre = [](int64_t, int) { return 0; };
       auto fin = [&](int64_t r, int c, f32x4 acc, int) {
-        if (!(skip0 && r == 0)) st<4>(out + r * ld_out + c, acc);   // (row 0: written by the reduction blocks)
+        if (!(skip0 && r == 0)) {                                   // (row 0: written by the reduction blocks)
+          st<4>(out + r * ld_out + c, acc);
+          am = amax_fold(am, acc);
+        }
       };
       if (K == 4) gather_walk<4>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else if (K == 3) gather_walk<3>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else if (K == 2) gather_walk<2>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else gather_walk<1>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      amax_commit(am, amax_out);
       return;
     }
   }
@@ -260,7 +289,9 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
       acc = acc + ld<VEC>(j >= 0 ? src + j * ld_src + c : gather_zero);
     }
     st<VEC>(out + r * ld_out + c, acc);
+    am = amax_fold(am, acc);
   }
+  amax_commit(am, amax_out);
 }
 
 // ------------------------------------------------------------------------ gather-sum with a fused epilogue
@@ -279,6 +310,7 @@ struct GatherEpi {
   float scale;
   int n_adds;          int64_t ld_add;
   const float* adds[GMAX];
+  float* amax_out;
 };
 
 // the 4 sign bits of columns c .. c+3 (c % 4 == 0) of row r in a rr_linear_args.mask_bits_out image
@@ -356,6 +388,7 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
                                                              int64_t ld_partial, const GatherEpi E) {
   using V = f32x4;
   const int64_t total = n_out * HV;
+  float am = 0.f;
   const int gblocks = row0_partial ? static_cast<int>(gridDim.x) - HV : static_cast<int>(gridDim.x);
   if (row0_partial != nullptr && static_cast<int>(blockIdx.x) >= gblocks) {      // padding-row reduction, see gather_sum_kernel
     __shared__ float red[256 * 4];
@@ -373,8 +406,13 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
       V v = (ld<4>(&red[threadIdx.x * 4]) + ld<4>(&red[(threadIdx.x + 64) * 4])) +
             (ld<4>(&red[(threadIdx.x + 128) * 4]) + ld<4>(&red[(threadIdx.x + 192) * 4]));
       v.x = rr_wave_sum(v.x); v.y = rr_wave_sum(v.y); v.z = rr_wave_sum(v.z); v.w = rr_wave_sum(v.w);
-      if (threadIdx.x == 0) st<4>(out + c, epi_apply<NADD>(E, 0, c, v));
+      if (threadIdx.x == 0) {
+        const f32x4 o = epi_apply<NADD>(E, 0, c, v);
+        st<4>(out + c, o);
+        am = amax_fold(am, o);
+      }
     }
+    amax_commit(am, E.amax_out);
     return;
   }
 #ifdef RR_GATHER_WALK
@@ -385,12 +423,17 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
       const bool skip0 = row0_partial != nullptr;
       auto pre = [&](int64_t r, int c) { return epi_load<NADD>(E, r, c); };
       auto fin = [&](int64_t r, int c, f32x4 acc, const EpiAux<NADD>& x) {
-        if (!(skip0 && r == 0)) st<4>(out + r * ld_out + c, epi_finish<NADD>(E, acc, x));
+        if (!(skip0 && r == 0)) {
+          const f32x4 o = epi_finish<NADD>(E, acc, x);
+          st<4>(out + r * ld_out + c, o);
+          am = amax_fold(am, o);
+        }
       };
       if (K == 4) gather_walk<4>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else if (K == 3) gather_walk<3>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else if (K == 2) gather_walk<2>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else gather_walk<1>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
+      amax_commit(am, E.amax_out);
       return;
     }
   }
@@ -414,8 +457,11 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
       const int32_t j = ir[k];
       acc = acc + ld<4>(j >= 0 ? src + j * ld_src + c : gather_zero);
     }
-    st<4>(out + r * ld_out + c, epi_apply<NADD>(E, r, c, acc));
+    const f32x4 o = epi_apply<NADD>(E, r, c, acc);
+    st<4>(out + r * ld_out + c, o);
+    am = amax_fold(am, o);
   }
+  amax_commit(am, E.amax_out);
 }
 
 // out[r] = sum_{j in [offs[r], offs[r+1])} src[idx[j]]  (CSR form: rows with arbitrarily many sources - the adjoint of a
@@ -706,40 +752,37 @@ __global__ void __launch_bounds__(256) segment_mean_bwd_vec_kernel(const float* 
 
 extern "C" {
 
-int rr_gather_sum_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
-                      int H, float* out, int64_t ld_out, rr_stream_t stream) {
+// row0_partial may be NULL (no padding-row reduction), amax_out may be NULL
+int rr_gather_sum_amax_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
+                           int H, const float* row0_partial, int64_t n_partial, int64_t ld_partial, float* out,
+                           int64_t ld_out, float* amax_out, rr_stream_t stream) {
   RR_CHECK_ARG(src && idx && out && n_src >= 0 && n_out >= 0 && K >= 1 && H >= 1 && ld_src >= H && ld_out >= H);
+  RR_CHECK_ARG(!row0_partial || (n_out >= 1 && n_partial >= 0 && ld_partial >= H));
   if (n_out == 0) return RR_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(out);
+  bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(out);
+  if (row0_partial) vec = vec && (ld_partial % 4 == 0) && rr_aligned16(row0_partial);
   if (vec) {
     const int HV = H / 4;
-    gather_sum_kernel<4><<<rr_grid_for(n_out * HV, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out,
-                                                                      nullptr, 0, 0);
+    gather_sum_kernel<4><<<rr_grid_for(n_out * HV, 256) + (row0_partial ? HV : 0), 256, 0, s>>>(
+        src, ld_src, idx, n_out, K, HV, out, ld_out, row0_partial, n_partial, ld_partial, amax_out);
   } else {
-    gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out,
-                                                                     nullptr, 0, 0);
+    gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256) + (row0_partial ? H : 0), 256, 0, s>>>(
+        src, ld_src, idx, n_out, K, H, out, ld_out, row0_partial, n_partial, ld_partial, amax_out);
   }
   return rr_launch_status();
+}
+
+int rr_gather_sum_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
+                      int H, float* out, int64_t ld_out, rr_stream_t stream) {
+  return rr_gather_sum_amax_f32(src, n_src, ld_src, idx, n_out, K, H, nullptr, 0, 0, out, ld_out, nullptr, stream);
 }
 
 int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
                              int H, const float* row0_partial, int64_t n_partial, int64_t ld_partial, float* out,
                              int64_t ld_out, rr_stream_t stream) {
-  RR_CHECK_ARG(src && idx && out && n_src >= 0 && n_out >= 1 && K >= 1 && H >= 1 && ld_src >= H && ld_out >= H);
-  RR_CHECK_ARG(row0_partial && n_partial >= 0 && ld_partial >= H);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && (ld_partial % 4 == 0) && rr_aligned16(src) &&
-                   rr_aligned16(out) && rr_aligned16(row0_partial);
-  if (vec) {
-    const int HV = H / 4;
-    gather_sum_kernel<4><<<rr_grid_for(n_out * HV, 256) + HV, 256, 0, s>>>(src, ld_src, idx, n_out, K, HV, out, ld_out,
-                                                                           row0_partial, n_partial, ld_partial);
-  } else {
-    gather_sum_kernel<1><<<rr_grid_for(n_out * H, 256) + H, 256, 0, s>>>(src, ld_src, idx, n_out, K, H, out, ld_out,
-                                                                         row0_partial, n_partial, ld_partial);
-  }
-  return rr_launch_status();
+  RR_CHECK_ARG(row0_partial && n_out >= 1);
+  return rr_gather_sum_amax_f32(src, n_src, ld_src, idx, n_out, K, H, row0_partial, n_partial, ld_partial, out, ld_out, nullptr, stream);
 }
 
 int rr_gather_sum_epi_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K, int H,
@@ -761,6 +804,7 @@ int rr_gather_sum_epi_f32(const float* src, int64_t n_src, int64_t ld_src, const
   E.scale = epi->mask_scale;
   E.n_adds = epi->n_adds;
   E.ld_add = epi->ld_add;
+  E.amax_out = epi->amax_out;
   for (int j = 0; j < GMAX; ++j) {
     E.adds[j] = j < epi->n_adds ? epi->adds[j] : nullptr;
     if (j < epi->n_adds) {

@@ -672,6 +672,42 @@ __device__ __forceinline__ void split_pair(float x, float y, uint32_t& p0, uint3
   p2 = cvt_pk_bf16(rx, ry);
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+// Two-term f16 form (w_packed = 3): S x = h + l with h = f16(S x), l = f16(S x - h) (round to nearest even; the remainder
+// is exact in f32), 22 significant bits of every operand, and  x w = h_x h_w + (h_x l_w + l_x h_w) + terms below
+// 2^-22 |x w|: three v_mfma_f32_16x16x32_f16 per k-step instead of six bf16 ones.  S is a power of two that puts the
+// tensor's largest magnitude below 2^15 (f16 has 5 exponent bits: the caller supplies the bound).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+// the power of two S with 2^14 <= S * bound < 2^15 (bounds outside 2^+-110, zero included, are clamped: nothing to protect
+// below, garbage in above), and its inverse
+__host__ __device__ __forceinline__ int rr_f16_exp(float bound) {
+  uint32_t u;
+  __builtin_memcpy(&u, &bound, 4);
+  int e = static_cast<int>((u >> 23) & 0xffu) - 127;     // bound < 2^(e+1)
+  return e < -110 ? -110 : (e > 110 ? 110 : e);
+}
+// |v| folded into a running maximum; a wave's maximum into a device float (one atomic per wave, and only while it can
+// still raise the slot: a stale read costs an atomic, never a result)
+__device__ __forceinline__ float rr_amax4(float m, f32x4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+// `seen` = the slot's value read EARLIER (before the stores whose magnitudes m collects): reading it here would wait for
+// every store issued before the read - loads and stores retire in issue order - and drain the store queue
+__device__ __forceinline__ void rr_amax_commit_wave(float m, float seen, float* out) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > seen) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+__device__ __forceinline__ float rr_pow2(int e) { return __uint_as_float(static_cast<uint32_t>(127 + e) << 23); }
+__device__ __forceinline__ void split_pair_h(float x, float y, float S, uint32_t& p0, uint32_t& p1) {
+  const f32x2 v = {x * S, y * S};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  p0 = __builtin_bit_cast(uint32_t, h);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
 
 // NTP: column tiles of the packed weight image; NT: column tiles of ONE workgroup (blockIdx.y picks tiles y * NT ...);
 // WAVES: 16-row groups per workgroup.  Instantiated: <19, 19, 12 waves> - one workgroup per CU (114 KB of LDS) covers all
@@ -680,11 +716,12 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 // both halves load and split the operand rows, 320 vs 236 us on the masked dX GEMM (profiles/r02_experiments.txt).
 // EPI: 0 = accumulator-layout epilogue, 1 = row-contiguous epilogue through LDS (12-wave geometry; chosen per launch,
 // see launch_split_one: separate instantiations keep each epilogue's registers out of the other's kernel)
-template <int NTP, int NT, int MODE, int WAVES, int EPI = 0>
+template <int NTP, int NT, int MODE, int WAVES, int EPI = 0, bool F16 = false>
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_kernel(const LinearParams P) {
   constexpr int BN = 16 * NT;
-  constexpr int PANEL = NT * 3 * 1024;                 // bytes of one k-step's weight image in LDS
-  constexpr int SRC_PANEL = NTP * 3 * 1024;            // ... and in the packed weights
+  constexpr int TERMS = F16 ? 2 : 3;                   // operand terms: three bf16 or two f16
+  constexpr int PANEL = NT * TERMS * 1024;             // bytes of one k-step's weight image in LDS
+  constexpr int SRC_PANEL = NTP * TERMS * 1024;            // ... and in the packed weights
   constexpr int S_BM = 16 * WAVES, S_THREADS = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS layout.  k-loop: two weight images [0, 2 * PANEL).  Epilogue of the 12-wave geometry (RS_EPI): the images' space
@@ -705,6 +742,17 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   const rr_linear_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fkq = lane >> 4;
+  // two-term f16 form: the operand scale from the caller's bounds (uniform: scalar loads), the weight's from its image
+  float xs = 1.f, ixs = 1.f, iws = 1.f;
+  if (F16) {
+    float b1 = (a.a1_amax ? *a.a1_amax : 0.f) + (a.a1_sub_amax ? *a.a1_sub_amax : 0.f);
+    if (MODE == 2 || MODE == 3) b1 *= fabsf(a.mask_scale);
+    const float b2 = a.a2_amax ? *a.a2_amax : 0.f;
+    const int e = rr_f16_exp(fmaxf(b1, b2));
+    xs = rr_pow2(14 - e);
+    ixs = rr_pow2(e - 14);
+    iws = 1.0f / a.w[static_cast<int64_t>(P.t1 + P.t2) * (SRC_PANEL / 4)];   // (a power of two: exact)
+  }
   RR_STAMP(0);
 #ifdef RR_TRACE
   if (rr_trace_buf && threadIdx.x == 0 && blockIdx.y == 0) {
@@ -776,11 +824,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       if (a.k2 > 0) rowp2 = a.a2 + m * a.lda2;
     }
   }
+  float dz_am = 0.f;                                   // largest |dz_out| this lane stored (rr_linear_args.dz_amax_out)
   float* dzrow = nullptr;                              // MODE 2 side output: dz_out (+)= masked operand
   if ((MODE == 2 || MODE == 3) && a.dz_out && row_ok && blockIdx.y == 0) dzrow = a.dz_out + m * a.ld_dz;
 
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
-  const float* const wlane = a.w + t0 * 768 + lane * 4;   // this workgroup's tiles of a step; 16 B per lane inside a 1 KiB block
+  const float* const wlane = a.w + t0 * (TERMS * 256) + lane * 4;   // this workgroup's tiles of a step; 16 B per lane inside a 1 KiB block
   const uint32_t lds0 = rr_lds_addr(reinterpret_cast<const float*>(smem));
 
   f32x4 acc[NT];
@@ -883,13 +932,20 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     const float* src = wlane + static_cast<int64_t>(s) * (SRC_PANEL / 4);
     const uint32_t dst = lds0 + (s & 1) * PANEL;
 #pragma unroll
-    for (int b0 = 0; b0 < NT * 3; b0 += WAVES) {
+    for (int b0 = 0; b0 < NT * TERMS; b0 += WAVES) {
       const int b = b0 + uwave;
-      if (b < nth * 3) rr_glds16(src + b * 256, dst + b * 1024);
+      if (b < nth * TERMS) rr_glds16(src + b * 256, dst + b * 1024);
     }
   };
   auto split8 = [&](const f32x4& v0, const f32x4& v1) {
     uint32_t t0, t1, t2;
+    if (F16) {
+      split_pair_h(v0.x, v0.y, xs, t0, t1); x0.x = t0; x1.x = t1;
+      split_pair_h(v0.z, v0.w, xs, t0, t1); x0.y = t0; x1.y = t1;
+      split_pair_h(v1.x, v1.y, xs, t0, t1); x0.z = t0; x1.z = t1;
+      split_pair_h(v1.z, v1.w, xs, t0, t1); x0.w = t0; x1.w = t1;
+      return;
+    }
     split_pair(v0.x, v0.y, t0, t1, t2); x0.x = t0; x1.x = t1; x2.x = t2;
     split_pair(v0.z, v0.w, t0, t1, t2); x0.y = t0; x1.y = t1; x2.y = t2;
     split_pair(v1.x, v1.y, t0, t1, t2); x0.z = t0; x1.z = t1; x2.z = t2;
@@ -961,14 +1017,36 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     split8(v0, v1);
     if (MODE == 2 || MODE == 3) {                      // side output (k1 % 4 == 0: chunks are whole).  Stored HERE, after the
       if (dzrow != nullptr && seg1) {                  // step's load wait: the store then has the whole next MFMA block to retire
-        if (kl < ks) *reinterpret_cast<f32x4*>(dzrow + kl) = v0;
-        if (kl + 4 < ks) *reinterpret_cast<f32x4*>(dzrow + kl + 4) = v1;
+        if (kl < ks) { *reinterpret_cast<f32x4*>(dzrow + kl) = v0; dz_am = rr_amax4(dz_am, v0); }
+        if (kl + 4 < ks) { *reinterpret_cast<f32x4*>(dzrow + kl + 4) = v1; dz_am = rr_amax4(dz_am, v1); }
       }
     }
   };
   auto mfma_block = [&](int s) {
     if (CAN_PERSIST && uwave >= nw) return;             // (uniform) a wave without rows in a short last block: no MFMAs, no LDS reads
     const u32x4* Ws = reinterpret_cast<const u32x4*>(smem + (s & 1) * PANEL) + lane;
+    if constexpr (F16) {
+      const f16x8 h0 = as_f16x8(x0), h1 = as_f16x8(x1);
+      u32x4 wa = Ws[0], wb = Ws[64];
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const f16x8 w0 = as_f16x8(wa), w1 = as_f16x8(wb);
+        if (j + 1 < NT) {
+          wa = Ws[((j + 1) * 2 + 0) * 64];
+          wb = Ws[((j + 1) * 2 + 1) * 64];
+        }
+        f32x4 c = acc[j];
+        if (j + 1 == NT && NT != NTP && !full) continue;
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, h0, c, 0, 0, 0);   // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h0, c, 0, 0, 0);
+        acc[j] = c;
+        if (j + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
+      return;
+    }
     const bf16x8 b0 = as_bf16x8(x0), b1 = as_bf16x8(x1), b2 = as_bf16x8(x2);
     // the three weight terms of tile j+1 are read while the six MFMAs of tile j run (pinned with sched_group_barrier:
     // left alone, the scheduler issues each ds_read right in front of its first use and waits for it)
@@ -1077,6 +1155,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // (persistent form: the lane id goes through an opaque asm per row block, so the epilogue's lane-derived offsets and
   // addresses are recomputed here - a few VALU instructions - instead of being hoisted out of the block loop, kept live
   // across the k-loop and spilled: 70 spilled registers / +60 MB of scratch writes per launch without this)
+  if (F16) {                                           // back from the scaled operands: two exact powers of two (one product
+#pragma unroll                                          // of them could leave the f32 exponent range where the result does not)
+    for (int i = 0; i < NT; ++i) acc[i] = (acc[i] * ixs) * iws;
+  }
   int lane_o = threadIdx.x;
 #ifndef RR_PERSIST_HOIST
   if (CAN_PERSIST) asm volatile("" : "+v"(lane_o));
@@ -1097,6 +1179,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   }
   const bool has_bias = a.bias != nullptr;
   const bool relu = a.act == RR_ACT_RELU;
+  float c_am = 0.f;                                    // largest |C| this lane stored (rr_linear_args.c_amax_out)
+  float c_seen = 0.f, dz_seen = 0.f;                   // the magnitude slots as they are now, read ahead of the stores
+  if (a.c_amax_out != nullptr) c_seen = *reinterpret_cast<volatile const float*>(a.c_amax_out);
+  if ((MODE == 2 || MODE == 3) && a.dz_amax_out != nullptr) dz_seen = *reinterpret_cast<volatile const float*>(a.dz_amax_out);
   auto finish = [&](f32x4 v, int n) -> f32x4 {
     if (relu) {
 #pragma unroll
@@ -1108,7 +1194,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = rr_hash_lane(w, e) >= P.drop_thr ? v[e] * P.keep_scale : 0.f;
     }
-    if (row_ok && n < a.N) *reinterpret_cast<f32x4*>(crow + n) = v;
+    if (row_ok && n < a.N) {
+      *reinterpret_cast<f32x4*>(crow + n) = v;
+      c_am = rr_amax4(c_am, v);
+    }
     return v;
   };
   float* prow = a.c_pre ? a.c_pre + mc * a.ld_pre : nullptr;
@@ -1213,7 +1302,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = rr_hash_lane(w, e) >= P.drop_thr ? v[e] * P.keep_scale : 0.f;
           }
-          if (ok) *reinterpret_cast<f32x4*>(a.c + mm * a.ldc + n) = v;
+          if (ok) {
+            *reinterpret_cast<f32x4*>(a.c + mm * a.ldc + n) = v;
+            c_am = rr_amax4(c_am, v);
+          }
           if (mb_on) {                                               // lanes l, l^1 hold the two halves of 8 consecutive columns
             uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
             if (c4 >= nqv) nib = 0u;                                  // columns past N: zero bits
@@ -1297,6 +1389,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #pragma unroll
     for (int i = 0; i < 5; ++i) d[i] = mb[i];
   }
+  if (a.c_amax_out != nullptr) rr_amax_commit_wave(c_am, c_seen, a.c_amax_out);
+  if ((MODE == 2 || MODE == 3) && a.dz_amax_out != nullptr && blockIdx.y == 0) {
+    rr_amax_commit_wave(dz_am, dz_seen, a.dz_amax_out);
+    dz_am = 0.f;
+  }
   if (cs_on) {                                         // one partial row per 64 rows (rr_linear_colsum_rows) = per 4 waves
     __syncthreads();
     static_assert(WAVES % 4 == 0 && (WAVES / 4) * (BN / 4) <= S_THREADS, "colsum slices");
@@ -1364,8 +1461,49 @@ __device__ __forceinline__ void pack_split_elem(const rr_pack_desc& q, int64_t e
   float v = 0.f;
   if (lc >= 0 && n < q.rows)
     v = q.transpose ? q.src[static_cast<int64_t>(lc) * q.ld_src + q.c0 + n] : q.src[static_cast<int64_t>(n) * q.ld_src + q.c0 + lc];
+  if (q.split == 2) {                                  // two f16 terms of S * L (S: pack_scale_kernel, behind the last image)
+    const int64_t nblk = static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * nt;
+    v *= q.dst[nblk * 512];
+    _Float16* d = reinterpret_cast<_Float16*>(q.dst) + blk * 2 * 512 + lane * 8 + el;
+    const _Float16 h = static_cast<_Float16>(v);
+    d[0] = h;
+    d[512] = static_cast<_Float16>(v - static_cast<float>(h));
+    return;
+  }
   uint16_t* d = reinterpret_cast<uint16_t*>(q.dst) + blk * 3 * 512 + lane * 8 + el;
   split_one(v, d[0], d[512], d[1024]);
+}
+
+// split = 2: S of each weight (one workgroup per weight walks its rows x (k1 + k2) elements; <= 600 x 983)
+__global__ void __launch_bounds__(1024) pack_scale_kernel(const PackMany P) {
+  const rr_pack_desc& q = P.d[blockIdx.x];
+  if (q.split != 2) return;
+  __shared__ float part[16];
+  const int K = q.k1 + q.k2;
+  const int64_t total = static_cast<int64_t>(q.rows) * K;
+  auto val = [&](int64_t e) -> float {                  // consecutive threads read consecutive memory in either orientation
+    const int n = q.transpose ? static_cast<int>(e % q.rows) : static_cast<int>(e / K);
+    const int lc = q.transpose ? static_cast<int>(e / q.rows) : static_cast<int>(e % K);
+    return fabsf(q.transpose ? q.src[static_cast<int64_t>(lc) * q.ld_src + q.c0 + n] : q.src[static_cast<int64_t>(n) * q.ld_src + q.c0 + lc]);
+  };
+  float m4[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t e = threadIdx.x;
+  for (; e + 3 * 1024 < total; e += 4 * 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m4[u] = fmaxf(m4[u], val(e + u * 1024));
+  }
+  for (; e < total; e += 1024) m4[0] = fmaxf(m4[0], val(e));
+  float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, part[i]);
+    const int64_t nblk = static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * split_nt(q.rows);
+    q.dst[nblk * 512] = rr_pow2(14 - rr_f16_exp(m));
+  }
 }
 
 __global__ void __launch_bounds__(256) pack_split_kernel(const PackMany P) {
@@ -1847,15 +1985,24 @@ __device__ __forceinline__ u32x4 tr_read8(const unsigned char* p, int rowbytes) 
 
 constexpr int SMT = 32;             // rows of M per staged tile on the split path
 
-template <bool HAS_MASK, bool HAS_SUB, int WTK>
+template <bool HAS_MASK, bool HAS_SUB, int WTK, bool F16 = false>
 __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradParams P) {
   constexpr int KB = 32 * WTK;                          // columns per k-block (160 / 128 / 96)
   constexpr int ZRB = 320;                              // bytes per row of a dZ term image (160 bf16)
   constexpr int XRB = WTK == 3 ? 192 : 320;             // X term image (WTK 4: 256 bytes of data + 64 of pad)
   constexpr int ZIMG = SMT * ZRB, XIMG = SMT * XRB;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * ZIMG + 3 * XIMG];
+  constexpr int TERMS = F16 ? 2 : 3;                    // three bf16 terms, or two f16 terms of the scaled operands (rr_wgrad_args.split = 2)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[TERMS * ZIMG + TERMS * XIMG];
   const rr_wgrad_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float zs = 1.f, xsc = 1.f, izs = 1.f, ixs = 1.f;     // F16: operand scales from the caller's bounds (uniform) and their inverses
+  if (F16) {
+    const int ez = rr_f16_exp((a.dy_amax ? *a.dy_amax : 0.f) * (HAS_MASK ? fabsf(a.mask_scale) : 1.f));
+    const float bx = fmaxf((a.x1_amax ? *a.x1_amax : 0.f) + (a.x1_sub_amax ? *a.x1_sub_amax : 0.f), a.x2_amax ? *a.x2_amax : 0.f);
+    const int ex = rr_f16_exp(fmaxf(bx, 1.0f));         // (the ones column of the extended X)
+    zs = rr_pow2(14 - ez); izs = rr_pow2(ez - 14);
+    xsc = rr_pow2(14 - ex); ixs = rr_pow2(ex - 14);
+  }
   const int nt = P.nblk_n * P.nblk_k;                   // XCD-aware mapping, see wgrad_fast_kernel
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile = slot % nt, chunk = (slot / nt) * 8 + xcd;
@@ -1944,8 +2091,16 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradPara
       if (HAS_SUB) xs[i] = ldg4((m_ok && ps != nullptr && kind == X_SEG1) ? ps + col : zero);
     }
   };
-  auto put = [&](unsigned char* img, int imgbytes, int rowbytes, int chunk8, f32x4 v) {   // split + three 8-byte stores
+  auto put = [&](unsigned char* img, int imgbytes, int rowbytes, int chunk8, f32x4 v, float sc) {   // split + three 8-byte stores
     uint32_t a0, a1, a2, b0, b1, b2;
+    if (F16) {
+      split_pair_h(v.x, v.y, sc, a0, a1);
+      split_pair_h(v.z, v.w, sc, b0, b1);
+      unsigned char* d = img + r * rowbytes + ((chunk8 * 8) ^ xr);
+      *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+      *reinterpret_cast<uint2*>(d + imgbytes) = make_uint2(a1, b1);
+      return;
+    }
     split_pair(v.x, v.y, a0, a1, a2);
     split_pair(v.z, v.w, b0, b1, b2);
     unsigned char* d = img + r * rowbytes + ((chunk8 * 8) ^ xr);
@@ -1961,7 +2116,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradPara
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = zm[i][e] > 0.f ? zv[i][e] * a.mask_scale : 0.f;
       }
-      put(lds, ZIMG, ZRB, g + 8 * i, z);
+      put(lds, ZIMG, ZRB, g + 8 * i, z, zs);
     }
 #pragma unroll
     for (int i = 0; i < WTK; ++i) {
@@ -1977,7 +2132,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradPara
           x[e] = u;
         }
       }
-      put(lds + 3 * ZIMG, XIMG, XRB, g + 8 * i, x);
+      put(lds + TERMS * ZIMG, XIMG, XRB, g + 8 * i, x, xsc);
     }
   };
 
@@ -1994,7 +2149,7 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradPara
   const int trow = 8 * fq + tq;
   const int txr = (fq & 1) << 5;
   const unsigned char* const zbase = lds + trow * ZRB + 8 * tp;
-  const unsigned char* const xbase = lds + 3 * ZIMG + trow * XRB + 8 * tp;
+  const unsigned char* const xbase = lds + TERMS * ZIMG + trow * XRB + 8 * tp;
 
   fetch_idx(0);
   issue(0);
@@ -2013,6 +2168,34 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradPara
 #pragma unroll
     for (int j0 = 0; j0 < WTK; j0 += JH) {
       asm volatile("" ::: "memory");                    // the second group RE-READS the dZ terms (no CSE across groups)
+      if constexpr (F16) {
+        f16x8 h0[JH], h1[JH];
+#pragma unroll
+        for (int jj = 0; jj < JH; ++jj) {
+          if (j0 + jj < WTK) {
+            const int xc = ((wk + 16 * (j0 + jj)) * 2) ^ txr;
+            h0[jj] = as_f16x8(tr_read8(xbase + xc, XRB));
+            h1[jj] = as_f16x8(tr_read8(xbase + XIMG + xc, XRB));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+          const int zc = ((wn + 16 * i) * 2) ^ txr;
+          const f16x8 a0 = as_f16x8(tr_read8(zbase + zc, ZRB));
+          const f16x8 a1 = as_f16x8(tr_read8(zbase + ZIMG + zc, ZRB));
+#pragma unroll
+          for (int jj = 0; jj < JH; ++jj) {
+            if (j0 + jj < WTK) {
+              f32x4 c = acc[i][j0 + jj];
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, h0[jj], c, 0, 0, 0);   // smallest terms first
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, h1[jj], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, h0[jj], c, 0, 0, 0);
+              acc[i][j0 + jj] = c;
+            }
+          }
+        }
+        continue;
+      }
       bf16x8 b0[JH], b1[JH], b2[JH];
 #pragma unroll
       for (int jj = 0; jj < JH; ++jj) {
@@ -2048,6 +2231,12 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradPara
   }
 
   float* slab = static_cast<float*>(a.workspace) + static_cast<int64_t>(chunk) * P.slab;
+  if (F16) {                                            // back from the scaled operands (two exact powers of two)
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WTK; ++j) acc[i][j] = (acc[i][j] * izs) * ixs;
+  }
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
 #pragma unroll
@@ -2200,15 +2389,67 @@ __global__ void __launch_bounds__(256) linear_rowdot_kernel(const float* __restr
 }
 
 
+// largest magnitude of a [rows, per_row (x 4 when VEC)] block, atomically maxed into *out (non-negative floats order like
+// their bit patterns; a NaN fails every comparison and is skipped)
+template <bool VEC>
+__global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, int64_t total, int per_row, int64_t ld, int tail,
+                                                   float* __restrict__ out) {
+  __shared__ float part[4];
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  const bool dense = VEC ? ld == 4 * static_cast<int64_t>(per_row) : ld == per_row;
+  auto at = [&](int64_t e) -> int64_t { return dense ? e * (VEC ? 4 : 1) : (e / per_row) * ld + (e % per_row) * (VEC ? 4 : 1); };
+  // VEC with cols % 4 != 0 (rows are 16-byte aligned, the last chunk of a row holds padding): its tail elements do not count
+  auto ldv = [&](int64_t e) -> f32x4 {
+    f32x4 v = ldg4(x + at(e));
+    if (tail != 0 && (e % per_row) == per_row - 1) {
+      if (tail < 2) v.y = 0.f;
+      if (tail < 3) v.z = 0.f;
+      v.w = 0.f;
+    }
+    return v;
+  };
+  int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  for (; e + 3 * stride < total; e += 4 * stride) {      // four independent loads in flight per thread
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (VEC) {
+        const f32x4 v = ldv(e + u * stride);
+        m[u] = fmaxf(fmaxf(m[u], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      } else {
+        m[u] = fmaxf(m[u], fabsf(x[at(e + u * stride)]));
+      }
+    }
+  }
+  for (; e < total; e += stride) {
+    if (VEC) {
+      const f32x4 v = ldv(e);
+      m[0] = fmaxf(fmaxf(m[0], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    } else {
+      m[0] = fmaxf(m[0], fabsf(x[at(e)]));
+    }
+  }
+  float r = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    r = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    // one atomic per workgroup, and only while it can still raise the slot (a stale read costs an atomic, never a result)
+    if (r > *reinterpret_cast<volatile float*>(out)) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(r));
+  }
+}
+
 // RR_EPI_MODE (A/B knob): 0 = accumulator-layout epilogue everywhere, 1 = row-contiguous where the epilogue READS (a
 // residual), 2 = row-contiguous everywhere it applies.  Measured (profiles/r03_experiments.txt): with a residual read
 // 223 -> 196 us per isolated 139k-row launch; store-only epilogues do not gain and pay the LDS round trip; inside a
 // training step (kernels of three streams interleaved on the chip) the difference is within the noise.
-template <int NTP, int NT, int MODE, int WAVES, int EPI>
+template <int NTP, int NT, int MODE, int WAVES, int EPI, bool F16>
 int launch_split_epi(const LinearParams& P, hipStream_t s) {
   // k-loop: two weight images + the bias slice; the 12-wave geometry's epilogue needs 12 transposition regions of
   // 8 x 77 float4, the column-sum / sign-bit staging and the bias slice (linear_split_kernel, "LDS layout")
-  constexpr int panel2 = 2 * NT * 3 * 1024, bn4 = 16 * NT * 4;
+  constexpr int panel2 = 2 * NT * (F16 ? 2 : 3) * 1024, bn4 = 16 * NT * 4;
   constexpr bool can_persist = MODE == 0 && WAVES == 12 && NT == NTP && EPI == 0;
   constexpr int smem = (WAVES == 12 ? ((12 * 8 * 77 * 16 > panel2 ? 12 * 8 * 77 * 16 : panel2) + 13 * bn4) : panel2 + bn4) +
                        (can_persist ? WAVES * 2048 : 0);       // + the persistent form's operand prefetch slots
@@ -2218,7 +2459,7 @@ int launch_split_epi(const LinearParams& P, hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return RR_ERR_LAUNCH;
   if (dev < 0 || dev >= 64 || !((configured.load(std::memory_order_acquire) >> dev) & 1u)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NTP, NT, MODE, WAVES, EPI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_split_kernel<NTP, NT, MODE, WAVES, EPI, F16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return RR_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) configured.fetch_or(uint64_t(1) << dev, std::memory_order_release);
@@ -2241,28 +2482,28 @@ int launch_split_epi(const LinearParams& P, hipStream_t s) {
       Q.persist = 1;
       // every CU an equal share of the 64-row units (the granularity of the column-sum partials)
       const dim3 grid(static_cast<unsigned>(cus), 1);
-      linear_split_kernel<NTP, NT, MODE, WAVES, EPI><<<grid, 64 * WAVES, smem, s>>>(Q);
+      linear_split_kernel<NTP, NT, MODE, WAVES, EPI, F16><<<grid, 64 * WAVES, smem, s>>>(Q);
       return rr_launch_status();
     }
   }
   const dim3 grid(static_cast<unsigned>(nblk), static_cast<unsigned>((NTP + NT - 1) / NT));
-  linear_split_kernel<NTP, NT, MODE, WAVES, EPI><<<grid, 64 * WAVES, smem, s>>>(P);
+  linear_split_kernel<NTP, NT, MODE, WAVES, EPI, F16><<<grid, 64 * WAVES, smem, s>>>(P);
   return rr_launch_status();
 }
-template <int NTP, int NT, int MODE, int WAVES>
+template <int NTP, int NT, int MODE, int WAVES, bool F16>
 int launch_split_one(const LinearParams& P, hipStream_t s) {
   if (WAVES == 12 && (MODE == 0 || MODE == 1)) {       // (the dX forms, MODE 2 / 3, never carry a residual)
     const bool rs = RR_EPI_MODE == 2 || (RR_EPI_MODE == 1 && P.a.residual != nullptr);
-    if (rs) return launch_split_epi<NTP, NT, MODE, WAVES, (WAVES == 12 && (MODE == 0 || MODE == 1)) ? 1 : 0>(P, s);
+    if (rs) return launch_split_epi<NTP, NT, MODE, WAVES, (WAVES == 12 && (MODE == 0 || MODE == 1)) ? 1 : 0, F16>(P, s);
   }
-  return launch_split_epi<NTP, NT, MODE, WAVES, 0>(P, s);
+  return launch_split_epi<NTP, NT, MODE, WAVES, 0, F16>(P, s);
 }
-template <int NTP, int NT, int WAVES>
+template <int NTP, int NT, int WAVES, bool F16 = false>
 int launch_split(const LinearParams& P, hipStream_t s) {
-  if (P.a.a_mask_bits) return launch_split_one<NTP, NT, 3, WAVES>(P, s);
-  if (P.a.a_mask) return launch_split_one<NTP, NT, 2, WAVES>(P, s);
-  if (P.a.a1_sub) return launch_split_one<NTP, NT, 1, WAVES>(P, s);
-  return launch_split_one<NTP, NT, 0, WAVES>(P, s);
+  if (P.a.a_mask_bits) return launch_split_one<NTP, NT, 3, WAVES, F16>(P, s);
+  if (P.a.a_mask) return launch_split_one<NTP, NT, 2, WAVES, F16>(P, s);
+  if (P.a.a1_sub) return launch_split_one<NTP, NT, 1, WAVES, F16>(P, s);
+  return launch_split_one<NTP, NT, 0, WAVES, F16>(P, s);
 }
 }  // namespace
 
@@ -2279,8 +2520,8 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   const rr_linear_args& a = *args;
   RR_CHECK_ARG(a.M >= 0 && a.N >= 1 && a.k1 >= 0 && a.k2 >= 0 && a.k1 + a.k2 >= 1);
   RR_CHECK_ARG(a.w && a.c && a.ldc >= a.N);
-  RR_CHECK_ARG(a.w_packed >= 0 && a.w_packed <= 2);
-  RR_CHECK_ARG(a.w_packed == 2 ? rr_aligned16(a.w)
+  RR_CHECK_ARG(a.w_packed >= 0 && a.w_packed <= 3);
+  RR_CHECK_ARG(a.w_packed >= 2 ? rr_aligned16(a.w)
                                : (a.w_packed ? (a.ldw == r16(a.k1) + r16(a.k2) && rr_aligned16(a.w)) : (a.ldw >= a.k1 + a.k2)));
   RR_CHECK_ARG(a.k1 == 0 || (a.a1 && a.lda1 >= a.k1));
   RR_CHECK_ARG(a.k2 == 0 || (a.a2 && a.lda2 >= a.k2));
@@ -2289,9 +2530,11 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   RR_CHECK_ARG(!a.residual || a.ldr >= a.N);
   RR_CHECK_ARG(!a.c_pre || a.ld_pre >= a.N);
   RR_CHECK_ARG(!a.dz_out || ((a.a_mask || a.a_mask_bits) && a.ld_dz >= a.k1));
-  RR_CHECK_ARG(!a.a_mask_bits || (a.w_packed == 2 && a.k2 == 0 && !a.a1_sub && !a.a1_idx && a.k1 % 4 == 0));
-  RR_CHECK_ARG(!a.mask_bits_out || (a.w_packed == 2 && a.N % 4 == 0));
+  RR_CHECK_ARG(!a.a_mask_bits || (a.w_packed >= 2 && a.k2 == 0 && !a.a1_sub && !a.a1_idx && a.k1 % 4 == 0));
+  RR_CHECK_ARG(!a.mask_bits_out || (a.w_packed >= 2 && a.N % 4 == 0));
   RR_CHECK_ARG(a.act == RR_ACT_NONE || a.act == RR_ACT_RELU);
+  RR_CHECK_ARG((!a.c_amax_out && !a.dz_amax_out) || a.w_packed >= 2);      // (the split kernels' epilogues only)
+  RR_CHECK_ARG(!a.dz_amax_out || a.dz_out);
   RR_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f);
   RR_CHECK_ARG(a.M < (int64_t(1) << 31) * BM);
   if (a.M == 0) return RR_OK;
@@ -2343,6 +2586,18 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
     RR_CHECK_ARG(a.colsum_w && a.ld_partial >= a.N);
     if (!fast || !vec_ok(a.colsum_partial, a.ld_partial)) return RR_ERR_ALIGN;
   }
+  if (a.w_packed == 3) {                              // two f16 terms: the same geometries
+    if (!fast || a.N > 608 || a.M >= (int64_t(1) << 31) * 128) return RR_ERR_ALIGN;
+    if (a.dz_accumulate) return RR_ERR_UNSUPPORTED;
+    RR_CHECK_ARG((a.k1 == 0 || a.a1_amax) && (a.k2 == 0 || a.a2_amax) && (!a.a1_sub || a.a1_sub_amax));
+    P.t1 = r32(a.k1) / SK;
+    P.t2 = r32(a.k2) / SK;
+    if (a.N <= 64) return launch_split<4, 4, 8, true>(P, s);
+    if (a.N <= 160) return launch_split<10, 10, 8, true>(P, s);
+    if (a.N <= 304 && a.M <= 8192) return launch_split<19, 5, 8, true>(P, s);
+    if (a.N <= 304) return launch_split<19, 19, 12, true>(P, s);
+    return launch_split<38, 19, 12, true>(P, s);
+  }
   if (a.w_packed == 2) {                              // split terms only exist in the straight-line geometry
     if (!fast || a.N > 608 || a.M >= (int64_t(1) << 31) * 128) return RR_ERR_ALIGN;
     if (a.dz_accumulate) return RR_ERR_UNSUPPORTED;
@@ -2381,7 +2636,7 @@ int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
   for (int i = 0; i < n; ++i) {
     const rr_pack_desc& q = descs[i];
     RR_CHECK_ARG(q.src && q.dst && q.rows >= 1 && q.c0 >= 0 && q.k1 >= 0 && q.k2 >= 0 && q.k1 + q.k2 >= 1 && q.ld_src >= 1);
-    RR_CHECK_ARG(q.split == 0 || (q.split == 1 && q.rows <= 608 && rr_aligned16(q.dst)));
+    RR_CHECK_ARG(q.split == 0 || ((q.split == 1 || q.split == 2) && q.rows <= 608 && rr_aligned16(q.dst)));
     P.d[i] = q;
     const int64_t total = q.split ? static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * split_nt(q.rows) * 512
                                   : static_cast<int64_t>(q.rows) * (r16(q.k1) + r16(q.k2));
@@ -2393,9 +2648,24 @@ int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
     pack_weights_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
   }
   if (biggest_split > 0) {
+    bool any_f16 = false;
+    for (int i = 0; i < n; ++i) any_f16 = any_f16 || descs[i].split == 2;
+    if (any_f16) pack_scale_kernel<<<static_cast<unsigned>(n), 1024, 0, static_cast<hipStream_t>(stream)>>>(P);
     dim3 grid(static_cast<unsigned>(rr_grid_for(biggest_split, 256, 64)), static_cast<unsigned>(n));
     pack_split_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
   }
+  return rr_launch_status();
+}
+
+int rr_amax_f32(const float* x, int64_t rows, int cols, int64_t ld, float* amax, rr_stream_t stream) {
+  RR_CHECK_ARG(x && amax && rows >= 0 && cols >= 1 && ld >= cols);
+  if (rows == 0) return RR_OK;
+  const bool vec = vec_ok(x, ld) && (cols + 3) / 4 * 4 <= ld;
+  const int64_t per_row = vec ? (cols + 3) / 4 : cols;
+  const int64_t total = rows * per_row;
+  const unsigned grid = static_cast<unsigned>(rr_grid_for((total + 3) / 4, 256, 1024));
+  if (vec) amax_kernel<true><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(x, total, static_cast<int>(per_row), ld, cols % 4, amax);
+  else amax_kernel<false><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(x, total, static_cast<int>(per_row), ld, 0, amax);
   return rr_launch_status();
 }
 
@@ -2429,7 +2699,8 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
   const int K = a.k1 + a.k2;
   WgradParams P;
   P.a = a;
-  RR_CHECK_ARG(a.split == 0 || a.split == 1);
+  RR_CHECK_ARG(a.split >= 0 && a.split <= 2);
+  RR_CHECK_ARG(a.split != 2 || (a.dy_amax && (a.k1 == 0 || a.x1_amax) && (a.k2 == 0 || a.x2_amax) && (!a.x1_sub || a.x1_sub_amax)));
   wgrad_plan(a.M, a.N, a.k1, a.k2, &P, a.split ? SMT : WMT);
   if (a.workspace_bytes < static_cast<size_t>(P.nchunks) * static_cast<size_t>(P.slab) * sizeof(float))
     return RR_ERR_WORKSPACE;
@@ -2454,16 +2725,23 @@ int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream) {
     const int per_blk = (P.kext + P.nblk_k - 1) / P.nblk_k;
     const int wtk = per_blk <= 96 ? 3 : (per_blk <= 128 ? 4 : 5);
     if (a.split) {                                      // (a request: the scalar-load geometry below stays on f32)
-#define RR_WSPLIT_LAUNCH(MASK, SUB)                                                        \
+#define RR_WSPLIT_LAUNCH(MASK, SUB, F16)                                                   \
     do {                                                                                   \
-      if (wtk == 3) wgrad_split_kernel<MASK, SUB, 3><<<grid, THREADS, 0, s>>>(P);          \
-      else if (wtk == 4) wgrad_split_kernel<MASK, SUB, 4><<<grid, THREADS, 0, s>>>(P);     \
-      else wgrad_split_kernel<MASK, SUB, 5><<<grid, THREADS, 0, s>>>(P);                   \
+      if (wtk == 3) wgrad_split_kernel<MASK, SUB, 3, F16><<<grid, THREADS, 0, s>>>(P);     \
+      else if (wtk == 4) wgrad_split_kernel<MASK, SUB, 4, F16><<<grid, THREADS, 0, s>>>(P); \
+      else wgrad_split_kernel<MASK, SUB, 5, F16><<<grid, THREADS, 0, s>>>(P);              \
     } while (0)
-      if (a.mask && a.x1_sub) RR_WSPLIT_LAUNCH(true, true);
-      else if (a.mask) RR_WSPLIT_LAUNCH(true, false);
-      else if (a.x1_sub) RR_WSPLIT_LAUNCH(false, true);
-      else RR_WSPLIT_LAUNCH(false, false);
+      if (a.split == 2) {
+        if (a.mask && a.x1_sub) RR_WSPLIT_LAUNCH(true, true, true);
+        else if (a.mask) RR_WSPLIT_LAUNCH(true, false, true);
+        else if (a.x1_sub) RR_WSPLIT_LAUNCH(false, true, true);
+        else RR_WSPLIT_LAUNCH(false, false, true);
+      } else {
+        if (a.mask && a.x1_sub) RR_WSPLIT_LAUNCH(true, true, false);
+        else if (a.mask) RR_WSPLIT_LAUNCH(true, false, false);
+        else if (a.x1_sub) RR_WSPLIT_LAUNCH(false, true, false);
+        else RR_WSPLIT_LAUNCH(false, false, false);
+      }
 #undef RR_WSPLIT_LAUNCH
     } else {
 #define RR_WGRAD_LAUNCH(MASK, SUB)                                                         \

@@ -80,10 +80,35 @@ int stream_wait(hipStream_t waiter, hipStream_t signaller) {
 // packed weight [rows, r16(k1)+r16(k2)] of W[:, c0 : c0+k1+k2] (transpose = 0) or of its transpose
 struct Packed { const float* w; int64_t ld; int mode; };   // mode = rr_linear_args.w_packed (1 f32 layout, 2 bf16 terms)
 
+// Two-f16-term GEMMs (RR_PLAN_F16X2_GEMM) need an upper bound of every operand tensor's magnitude.  The plan keeps one
+// float per tensor in a block of the workspace (zeroed at the start of the forward / of the backward's own part), found
+// by one rr_amax_f32 pass on the stream of the tensor's FIRST consumer and shared by every later one (a forward
+// activation's slot serves its weight gradient in the backward: the workspace is kept).  Tensors are known by address:
+// every arena allocation and the step's input arrays are recorded with their shape.
+constexpr int MAX_TENSORS = 768, MAX_AMAX = 256;
+struct TensorRec { const float* p; int64_t rows, cols, ld; float* amax; };
+
 struct Ctx {
   bool launch;                        // false: layout pass only (no kernel is enqueued)
   int status;
   Arena ar;
+  bool f16;                           // split GEMMs on two f16 terms (needs split)
+  float* amax_base;                   // MAX_AMAX floats (null in a measuring pass)
+  int namax, ntr;
+  TensorRec tr[MAX_TENSORS];
+  float* alloc(int64_t rows, int64_t cols) {            // arena tensor, remembered for amax_of()
+    float* p = ar.f(rows, cols);
+    if (f16 && p != nullptr && !ar.overflow) reg(p, rows, cols, cols);
+    return p;
+  }
+  void reg(const float* p, int64_t rows, int64_t cols, int64_t ld) {
+    if (!f16 || p == nullptr || ar.base == nullptr) return;
+    for (int i = 0; i < ntr; ++i)
+      if (tr[i].p == p) return;
+    if (ntr == MAX_TENSORS) { fail(RR_ERR_UNSUPPORTED); return; }
+    tr[ntr].p = p; tr[ntr].rows = rows; tr[ntr].cols = cols; tr[ntr].ld = ld; tr[ntr].amax = nullptr;
+    ++ntr;
+  }
   Streams s;
   bool use_side, use_aux, aux_bwd;
   bool train;                         // RR_PLAN_TRAIN: the forward packs the backward's transposed weights too
@@ -103,6 +128,39 @@ struct Ctx {
     }                                                                                             \
   } while (0)
 
+// the magnitude slot of tensor t; the first request enqueues its pass on `st` (where t's producer ran or was waited for)
+const float* amax_of(Ctx& c, const float* t, hipStream_t st) {
+  if (!c.f16 || t == nullptr || c.ar.base == nullptr) return nullptr;
+  for (int i = 0; i < c.ntr; ++i) {
+    TensorRec& r = c.tr[i];
+    if (r.p != t) continue;
+    if (r.amax == nullptr) {
+      if (c.namax == MAX_AMAX) { c.fail(RR_ERR_UNSUPPORTED); return nullptr; }
+      r.amax = c.amax_base + c.namax++;
+      RR_TRY(c, rr_amax_f32(r.p, r.rows, static_cast<int>(r.cols), r.ld, r.amax, st));
+    }
+    return r.amax;
+  }
+  if (getenv("RR_PLAN_DEBUG")) fprintf(stderr, "[rr plan] amax_of: unknown tensor %p\n", static_cast<const void*>(t));
+  c.fail(RR_ERR_ARG);
+  return nullptr;
+}
+
+// the slot of a tensor whose PRODUCER maxes its magnitude in as it stores (no pass); null when the mode does not need one
+float* amax_claim(Ctx& c, const float* t) {
+  if (!c.f16 || t == nullptr || c.ar.base == nullptr) return nullptr;
+  for (int i = 0; i < c.ntr; ++i) {
+    TensorRec& r = c.tr[i];
+    if (r.p != t) continue;
+    if (r.amax == nullptr) {
+      if (c.namax == MAX_AMAX) { c.fail(RR_ERR_UNSUPPORTED); return nullptr; }
+      r.amax = c.amax_base + c.namax++;
+    }
+    return r.amax;
+  }
+  return nullptr;
+}
+
 void flush_packs(Ctx& c, hipStream_t st) {
   if (c.npq > 0) RR_TRY(c, rr_pack_weights_f32(c.pq, c.npq, st));
   c.npq = 0;
@@ -115,25 +173,25 @@ Packed pack(Ctx& c, const rr_linear_w& L, int transpose, int rows, int c0, int k
   float* dst;
   if (split) {
     p.ld = 0;
-    p.mode = 2;
-    dst = c.ar.f(1, static_cast<int64_t>(rr_split_weight_bytes(rows, k1, k2) / 4));
+    p.mode = c.f16 ? 3 : 2;
+    dst = c.alloc(1, static_cast<int64_t>(rr_split_weight_bytes(rows, k1, k2) / 4));
   } else {
     p.ld = rr_packed_weight_ld(k1, k2);
     p.mode = 1;
-    dst = c.ar.f(rows, p.ld);
+    dst = c.alloc(rows, p.ld);
   }
   p.w = dst;
   if (c.npq == RR_MAX_PACK) flush_packs(c, st);
   rr_pack_desc& q = c.pq[c.npq++];
   q.src = L.w; q.ld_src = L.ldw; q.transpose = transpose; q.rows = rows; q.c0 = c0; q.k1 = k1; q.k2 = k2; q.dst = dst;
-  q.split = split ? 1 : 0;
+  q.split = split ? (c.f16 ? 2 : 1) : 0;
   return p;
 }
 
 // sign-bit image of an [rows, N] activation produced by a split GEMM (null: the consumer reads the f32 tensor instead)
 uint8_t* mask_bits(Ctx& c, const Packed& producer, int64_t rows, int N) {
-  if (producer.mode != 2) return nullptr;
-  return reinterpret_cast<uint8_t*>(c.ar.f(rows, rr_mask_bits_row_bytes(N) / 4));
+  if (producer.mode < 2) return nullptr;
+  return reinterpret_cast<uint8_t*>(c.alloc(rows, rr_mask_bits_row_bytes(N) / 4));
 }
 
 rr_linear_args LA(int64_t M, int N) {
@@ -146,16 +204,29 @@ rr_linear_args LA(int64_t M, int N) {
   return a;
 }
 
+// rr_linear_f32 with the operand bounds of the two-f16-term path filled in
+void lin(Ctx& c, rr_linear_args& a, hipStream_t st) {
+  if (a.w_packed == 3) {
+    if (a.k1 > 0) a.a1_amax = amax_of(c, a.a1, st);
+    if (a.a1_sub) a.a1_sub_amax = amax_of(c, a.a1_sub, st);
+    if (a.k2 > 0) a.a2_amax = amax_of(c, a.a2, st);
+    a.c_amax_out = amax_claim(c, a.c);                  // what the next GEMM needs of this one's outputs
+    if (a.dz_out) a.dz_amax_out = amax_claim(c, a.dz_out);
+  }
+  RR_TRY(c, rr_linear_f32(&a, st));
+}
+
 // Packs are queued and issued together (rr_pack_weights_f32: one launch for up to 16 weights) by flush_packs().
 
 void set_w(rr_linear_args& a, const Packed& p) {
   a.w = p.w; a.ldw = p.ld; a.w_packed = p.mode;
-  if (p.mode != 2) a.a_mask_bits = nullptr;            // only the split GEMM reads sign-bit masks (a_mask stays set)
+  if (p.mode < 2) a.a_mask_bits = nullptr;            // only the split GEMM reads sign-bit masks (a_mask stays set)
 }
 
 void gather_sum(Ctx& c, const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K, int H,
                 float* out, int64_t ld_out, hipStream_t st, const float* part = nullptr, int64_t n_part = 0, int64_t ld_part = 0) {
-  if (part) RR_TRY(c, rr_gather_sum_padrow_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, st));
+  if (c.f16) RR_TRY(c, rr_gather_sum_amax_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, amax_claim(c, out), st));
+  else if (part) RR_TRY(c, rr_gather_sum_padrow_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, st));
   else RR_TRY(c, rr_gather_sum_f32(src, n_src, ld_src, idx, n_out, K, H, out, ld_out, st));
 }
 
@@ -171,15 +242,22 @@ void gather_epi(Ctx& c, const float* src, int64_t n_src, const int32_t* idx, int
   e.n_adds = n_adds;
   e.ld_add = H;
   for (int j = 0; j < n_adds; ++j) e.adds[j] = adds[j];
+  e.amax_out = amax_claim(c, out);
   RR_TRY(c, rr_gather_sum_epi_f32(src, n_src, H, idx, n_out, K, H, part, n_part, r4(H), &e, out, H, st));
 }
 
 // weight gradient on the side stream: waits for the main stream's work so far (its operands), returns immediately
 void wgrad(Ctx& c, rr_wgrad_args& a) {
   const size_t wb = rr_linear_wgrad_workspace_bytes(a.M, a.N, a.k1 + a.k2);
-  a.workspace = c.ar.f(1, static_cast<int64_t>((wb + 3) / 4));
+  a.workspace = c.alloc(1, static_cast<int64_t>((wb + 3) / 4));
   a.workspace_bytes = wb;
-  a.split = (c.split && a.M >= 8192) ? 1 : 0;           // the FFN head (one row per molecule) stays on the f32 matrix core
+  a.split = (c.split && a.M >= 8192) ? (c.f16 ? 2 : 1) : 0;   // the FFN head (one row per molecule) stays on the f32 matrix core
+  if (a.split == 2) {                                   // bounds on the chain's stream, BEFORE the side stream waits for it
+    a.dy_amax = amax_of(c, a.dy, c.cur);
+    if (a.k1 > 0) a.x1_amax = amax_of(c, a.x1, c.cur);
+    if (a.x1_sub) a.x1_sub_amax = amax_of(c, a.x1_sub, c.cur);
+    if (a.k2 > 0) a.x2_amax = amax_of(c, a.x2, c.cur);
+  }
   if (!c.launch || c.status != RR_OK) return;
   hipStream_t st = c.use_side ? c.s.side : c.cur;
   if (c.use_side) c.fail(stream_wait(c.s.side, c.cur));
@@ -245,20 +323,20 @@ struct Plan {
 void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk, float p, uint64_t seed, EncSaved& S,
                  hipStream_t st) {
   const int H = m.H, depth = m.depth, FB = m.bond_fdim;
-  float* inp = c.ar.f(g.nB, H);
-  S.msgs[0] = c.ar.f(g.nB, H);
+  float* inp = c.alloc(g.nB, H);
+  S.msgs[0] = c.alloc(g.nB, H);
   {
     rr_linear_args a = LA(g.nB, H);
     a.a1 = g.f_bonds; a.lda1 = g.ld_fb; a.k1 = FB;
     set_w(a, pk.enc_wi); a.bias = m.enc_wi.b; a.act = RR_ACT_RELU;
     a.c = S.msgs[0]; a.ldc = H; a.c_pre = inp; a.ld_pre = H;
     S.bits[0] = mask_bits(c, pk.enc_wi, g.nB, H); a.mask_bits_out = S.bits[0];           // relu'(input) for the backward
-    RR_TRY(c, rr_linear_f32(&a, st));                                                   // :80-81
+    lin(c, a, st);                                                   // :80-81
   }
   for (int it = 0; it < depth - 1; ++it) {                                              // :84
-    S.amsgs[it] = c.ar.f(g.nA, H);
+    S.amsgs[it] = c.alloc(g.nA, H);
     gather_sum(c, S.msgs[it], g.nB, H, g.a2b, g.nA, g.K, H, S.amsgs[it], H, st);       // :89-90
-    S.msgs[it + 1] = c.ar.f(g.nB, H);
+    S.msgs[it + 1] = c.alloc(g.nB, H);
     rr_linear_args a = LA(g.nB, H);
     a.a1 = S.amsgs[it]; a.lda1 = H; a.k1 = H; a.a1_idx = g.b2a;
     a.a1_sub = S.msgs[it]; a.lda1_sub = H; a.a1_sub_idx = g.b2revb;
@@ -266,52 +344,52 @@ void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk
     a.drop_p = p; a.drop_seed = site_seed(seed, it);
     a.c = S.msgs[it + 1]; a.ldc = H;
     S.bits[it + 1] = mask_bits(c, pk.enc_wh, g.nB, H); a.mask_bits_out = S.bits[it + 1];
-    RR_TRY(c, rr_linear_f32(&a, st));                                                   // :91-97
+    lin(c, a, st);                                                   // :91-97
   }
-  S.a_last = c.ar.f(g.nA, H);
+  S.a_last = c.alloc(g.nA, H);
   gather_sum(c, S.msgs[depth - 1], g.nB, H, g.a2b, g.nA, g.K, H, S.a_last, H, st);     // :101-102
-  S.h = c.ar.f(g.nA, H);
+  S.h = c.alloc(g.nA, H);
   rr_linear_args a = LA(g.nA, H);
   a.a1 = g.f_atoms; a.lda1 = g.ld_fa; a.k1 = m.atom_fdim; a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
   set_w(a, pk.enc_wo); a.bias = m.enc_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 1000);
   a.c = S.h; a.ldc = H;
   S.bits_h = mask_bits(c, pk.enc_wo, g.nA, H); a.mask_bits_out = S.bits_h;
-  RR_TRY(c, rr_linear_f32(&a, st));                                                     // :103-105
+  lin(c, a, st);                                                     // :103-105
 }
 
 // the same for a batch whose molecules repeat: the deterministic prefix runs once per distinct molecule
 void mpn_forward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_graph& g, const int32_t* bmap,
                         const PackedW& pk, float p, uint64_t seed, EncSaved& S, hipStream_t st) {
   const int H = m.H, depth = m.depth, FB = m.bond_fdim;
-  float* inp_u = c.ar.f(gu.nB, H);
-  S.msg0_u = c.ar.f(gu.nB, H);
+  float* inp_u = c.alloc(gu.nB, H);
+  S.msg0_u = c.alloc(gu.nB, H);
   {
     rr_linear_args a = LA(gu.nB, H);
     a.a1 = gu.f_bonds; a.lda1 = gu.ld_fb; a.k1 = FB;
     set_w(a, pk.enc_wi); a.bias = m.enc_wi.b; a.act = RR_ACT_RELU;
     a.c = S.msg0_u; a.ldc = H; a.c_pre = inp_u; a.ld_pre = H;
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
   }
-  S.a0_u = c.ar.f(gu.nA, H);
+  S.a0_u = c.alloc(gu.nA, H);
   gather_sum(c, S.msg0_u, gu.nB, H, gu.a2b, gu.nA, gu.K, H, S.a0_u, H, st);
-  float* z1_u = c.ar.f(gu.nB, H);
+  float* z1_u = c.alloc(gu.nB, H);
   {
     rr_linear_args a = LA(gu.nB, H);
     a.a1 = S.a0_u; a.lda1 = H; a.k1 = H; a.a1_idx = gu.b2a;
     a.a1_sub = S.msg0_u; a.lda1_sub = H; a.a1_sub_idx = gu.b2revb;
     set_w(a, pk.enc_wh); a.bias = m.enc_wh.b; a.residual = inp_u; a.ldr = H; a.act = RR_ACT_RELU;
     a.c = z1_u; a.ldc = H;
-    RR_TRY(c, rr_linear_f32(&a, st));                                                   // pre-dropout, shared
+    lin(c, a, st);                                                   // pre-dropout, shared
   }
   S.msgs[0] = nullptr;
-  S.msgs[1] = c.ar.f(g.nB, H);
+  S.msgs[1] = c.alloc(g.nB, H);
   RR_TRY(c, rr_gather_dropout_f32(z1_u, gu.nB, H, bmap, g.nB, H, p, site_seed(seed, 0), S.msgs[1], H, st));   // per-copy masks
   S.z1_u = z1_u;
   S.seed0 = site_seed(seed, 0);
   for (int it = 1; it < depth - 1; ++it) {
-    S.amsgs[it] = c.ar.f(g.nA, H);
+    S.amsgs[it] = c.alloc(g.nA, H);
     gather_sum(c, S.msgs[it], g.nB, H, g.a2b, g.nA, g.K, H, S.amsgs[it], H, st);
-    S.msgs[it + 1] = c.ar.f(g.nB, H);
+    S.msgs[it + 1] = c.alloc(g.nB, H);
     rr_linear_args a = LA(g.nB, H);
     a.a1 = S.amsgs[it]; a.lda1 = H; a.k1 = H; a.a1_idx = g.b2a;
     a.a1_sub = S.msgs[it]; a.lda1_sub = H; a.a1_sub_idx = g.b2revb;
@@ -319,17 +397,17 @@ void mpn_forward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_
     a.drop_p = p; a.drop_seed = site_seed(seed, it);
     a.c = S.msgs[it + 1]; a.ldc = H;
     S.bits[it + 1] = mask_bits(c, pk.enc_wh, g.nB, H); a.mask_bits_out = S.bits[it + 1];
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
   }
-  S.a_last = c.ar.f(g.nA, H);
+  S.a_last = c.alloc(g.nA, H);
   gather_sum(c, S.msgs[depth - 1], g.nB, H, g.a2b, g.nA, g.K, H, S.a_last, H, st);
-  S.h = c.ar.f(g.nA, H);
+  S.h = c.alloc(g.nA, H);
   rr_linear_args a = LA(g.nA, H);
   a.a1 = g.f_atoms; a.lda1 = g.ld_fa; a.k1 = m.atom_fdim; a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
   set_w(a, pk.enc_wo); a.bias = m.enc_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 1000);
   a.c = S.h; a.ldc = H;
   S.bits_h = mask_bits(c, pk.enc_wo, g.nA, H); a.mask_bits_out = S.bits_h;
-  RR_TRY(c, rr_linear_f32(&a, st));
+  lin(c, a, st);
 }
 
 // MPNDiff.forward (models/mpn.py:170-240): atom_features = x - x_sub[x_sub_idx]
@@ -337,8 +415,8 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
                      const float* x_sub, const int32_t* x_sub_idx, const float* feat, int F, uint64_t out_seed, DiffSaved& S,
                      hipStream_t st) {
   const int H = m.H, depth = m.diff_depth, FB = m.bond_fdim;
-  float* inp = c.ar.f(g.nA, H);
-  S.msgs[0] = c.ar.f(g.nA, H);
+  float* inp = c.alloc(g.nA, H);
+  S.msgs[0] = c.alloc(g.nA, H);
   {
     rr_linear_args a = LA(g.nA, H);
     a.a1 = x; a.lda1 = H; a.k1 = H; a.a1_sub = x_sub; a.lda1_sub = H; a.a1_sub_idx = x_sub_idx;
@@ -346,37 +424,37 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
     a.drop_p = depth == 0 ? p : 0.f; a.drop_seed = site_seed(seed, 2000);              // :221 (depth 0: dropout(message))
     a.c = S.msgs[0]; a.ldc = H; a.c_pre = inp; a.ld_pre = H;
     S.bits[0] = mask_bits(c, pk.dif_wi, g.nA, H); a.mask_bits_out = S.bits[0];
-    RR_TRY(c, rr_linear_f32(&a, st));                                                   // :194-195
+    lin(c, a, st);                                                   // :194-195
   }
   if (depth > 0) {
     for (int it = 0; it < depth - 1; ++it) {                                            // :199
-      S.amsgs[it] = c.ar.f(g.nA, H);
+      S.amsgs[it] = c.alloc(g.nA, H);
       gather_sum(c, S.msgs[it], g.nA, H, g.a2a, g.nA, g.K, H, S.amsgs[it], H, st);     // :201
-      S.msgs[it + 1] = c.ar.f(g.nA, H);
+      S.msgs[it + 1] = c.alloc(g.nA, H);
       rr_linear_args a = LA(g.nA, H);
       a.a1 = S.amsgs[it]; a.lda1 = H; a.k1 = H; a.a2 = g.fb_sum; a.lda2 = g.ld_fbs; a.k2 = FB;
       set_w(a, pk.dif_wh); a.bias = m.dif_wh.b; a.residual = inp; a.ldr = H; a.act = RR_ACT_RELU;
       a.drop_p = p; a.drop_seed = site_seed(seed, 2001 + it);
       a.c = S.msgs[it + 1]; a.ldc = H;
       S.bits[it + 1] = mask_bits(c, pk.dif_wh, g.nA, H); a.mask_bits_out = S.bits[it + 1];
-      RR_TRY(c, rr_linear_f32(&a, st));                                                 // :202-213
+      lin(c, a, st);                                                 // :202-213
     }
-    S.a_last = c.ar.f(g.nA, H);
+    S.a_last = c.alloc(g.nA, H);
     gather_sum(c, S.msgs[depth - 1], g.nA, H, g.a2a, g.nA, g.K, H, S.a_last, H, st);   // :215-216
-    S.hid = c.ar.f(g.nA, H);
+    S.hid = c.alloc(g.nA, H);
     rr_linear_args a = LA(g.nA, H);
     a.a1 = x; a.lda1 = H; a.k1 = H; a.a1_sub = x_sub; a.lda1_sub = H; a.a1_sub_idx = x_sub_idx;
     a.a2 = S.a_last; a.lda2 = H; a.k2 = H;
     set_w(a, pk.dif_wo); a.bias = m.dif_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 3000);
     a.c = S.hid; a.ldc = H;
     S.bits_hid = mask_bits(c, pk.dif_wo, g.nA, H); a.mask_bits_out = S.bits_hid;
-    RR_TRY(c, rr_linear_f32(&a, st));                                                   // :217-219
+    lin(c, a, st);                                                   // :217-219
   } else {
     S.a_last = nullptr;
     S.hid = S.msgs[0];
   }
   S.ld_vecs = r4(H + F);
-  S.vecs = c.ar.f(g.M, S.ld_vecs);
+  S.vecs = c.alloc(g.M, S.ld_vecs);
   RR_TRY(c, rr_segment_mean_fwd_f32(S.hid, H, g.a_scope, g.M, H, feat, F, p, out_seed, S.vecs, S.ld_vecs, st));   // :224-238
 }
 
@@ -387,20 +465,20 @@ void ffn_forward(Ctx& c, const rr_model& m, const PackedW& pk, int64_t M, float 
   for (int li = 0; li < m.n_ffn - 1; ++li) {
     const rr_linear_w& L = m.ffn[li];
     S.ld_hs[li + 1] = r4(L.out);
-    S.hs[li + 1] = c.ar.f(M, S.ld_hs[li + 1]);
+    S.hs[li + 1] = c.alloc(M, S.ld_hs[li + 1]);
     rr_linear_args a = LA(M, L.out);
     a.a1 = S.hs[li]; a.lda1 = S.ld_hs[li]; a.k1 = L.in;
     set_w(a, pk.ffn[li]); a.bias = L.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 4000 + li);
     a.c = S.hs[li + 1]; a.ldc = S.ld_hs[li + 1];
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
   }
   const rr_linear_w& L = m.ffn[m.n_ffn - 1];
-  S.raw = m.head == 0 ? out : c.ar.f(M, L.out);
+  S.raw = m.head == 0 ? out : c.alloc(M, L.out);
   rr_linear_args a = LA(M, L.out);
   a.a1 = S.hs[m.n_ffn - 1]; a.lda1 = S.ld_hs[m.n_ffn - 1]; a.k1 = L.in;
   set_w(a, pk.ffn[m.n_ffn - 1]); a.bias = L.b;
   a.c = S.raw; a.ldc = L.out;
-  RR_TRY(c, rr_linear_f32(&a, st));
+  lin(c, a, st);
   if (m.head != 0) RR_TRY(c, rr_head_fwd_f32(S.raw, M, L.out, m.head, out, st));
 }
 
@@ -425,6 +503,20 @@ void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
   const int H = m.H;
   const float p = s.drop_p;
   hipStream_t main = c.s.main;
+  c.ntr = 0;
+  c.namax = 0;
+  c.amax_base = nullptr;
+  if (c.f16) {
+    c.amax_base = c.ar.f(1, MAX_AMAX);
+    if (c.launch && c.status == RR_OK && hipMemsetAsync(c.amax_base, 0, MAX_AMAX * sizeof(float), main) != hipSuccess) c.fail(RR_ERR_LAUNCH);
+    const rr_graph* gs[3] = {&s.p, &s.r, &s.u};
+    for (int i = 0; i < (s.mode == RR_STEP_PREFIX ? 3 : 2); ++i) {
+      const rr_graph& g = *gs[i];
+      c.reg(g.f_bonds, g.nB, m.bond_fdim, g.ld_fb);
+      c.reg(g.f_atoms, g.nA, m.atom_fdim, g.ld_fa);
+      c.reg(g.fb_sum, g.nA, m.bond_fdim, g.ld_fbs);
+    }
+  }
   // packed weights (shared by both encoder passes): once, on the main stream
   P.pk.enc_wi = pack(c, m.enc_wi, 0, H, 0, m.bond_fdim, 0, main);
   if (m.depth > 1) P.pk.enc_wh = pack(c, m.enc_wh, 0, H, 0, H, 0, main);
@@ -453,7 +545,7 @@ struct EncGrads { float *wi, *bi, *wh, *bh, *wo, *bo; };
 
 // d message = adjoint of the bond message (one gather over b2b_t; row 0 from the GEMM's weighted column sums)
 float* bond_adjoint(Ctx& c, const rr_graph& g, int H, const float* d_min, const float* part, hipStream_t st) {
-  float* d_msg = c.ar.f(g.nB, H);
+  float* d_msg = c.alloc(g.nB, H);
   gather_sum(c, d_min, g.nB, H, g.b2b_t, g.nB, g.Kb, H, d_msg, H, st, part, rr_linear_colsum_rows(g.nB), r4(H));
   return d_msg;
 }
@@ -464,16 +556,16 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
   const int H = m.H, depth = m.depth;
   const float ks = 1.0f / (1.0f - p);
   hipStream_t st = c.cur;
-  float* dz_o = c.ar.f(g.nA, H);
-  float* d_a = c.ar.f(g.nA, H);
-  float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
+  float* dz_o = c.alloc(g.nA, H);
+  float* d_a = c.alloc(g.nA, H);
+  float* part = c.alloc(rr_linear_colsum_rows(g.nA), r4(H));
   {
     rr_linear_args a = LA(g.nA, H);
     a.a1 = dH; a.lda1 = H; a.k1 = H; a.a_mask = S.h; a.a_mask_bits = S.bits_h; a.ld_mask = H; a.mask_scale = sign * ks;
     a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_t);
     a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
     a.c = d_a; a.ldc = H;
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
   }
   {
     rr_wgrad_args w = WA(g.nA, H, dz_o, H, G.wo, m.enc_wo.in, G.bo, accumulate);
@@ -486,7 +578,7 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
   // and the last gather also adds every iteration's dZ: its output is d input (models/mpn.py:94), no pass of its own.
   const float* dzs[MAXD];
   int ndz = 0;
-  float* cur = c.ar.f(g.nB, H);        // dZ of iteration depth-2 (or d input when depth == 1)
+  float* cur = c.alloc(g.nB, H);        // dZ of iteration depth-2 (or d input when depth == 1)
   {
     const int top = depth - 1;         // the activation whose pattern masks this gradient: msgs[depth-1]
     gather_epi(c, d_a, g.nA, g.b2t, g.nB, 1, H, cur, st, part, rr_linear_colsum_rows(g.nA), true, S.msgs[top], S.bits[top],
@@ -494,20 +586,20 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
   }
   for (int it = depth - 2; it >= 0; --it) {
     float* dz = cur;
-    float* d_min = c.ar.f(g.nB, H);
-    float* partb = c.ar.f(rr_linear_colsum_rows(g.nB), r4(H));
+    float* d_min = c.alloc(g.nB, H);
+    float* partb = c.alloc(rr_linear_colsum_rows(g.nB), r4(H));
     rr_linear_args a = LA(g.nB, H);
     a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
     a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
     a.c = d_min; a.ldc = H;
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
     rr_wgrad_args w = WA(g.nB, H, dz, H, G.wh, H, G.bh, (accumulate || it != depth - 2) ? 1 : 0);
     w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x1_idx = g.b2a; w.x1_sub = S.msgs[it]; w.ldx1_sub = H; w.x1_sub_idx = g.b2revb;
     wgrad(c, w);
     dzs[ndz++] = dz;
     // adjoint of the bond message (one gather over b2b_t; row 0 from the GEMM's weighted column sums), masked by msgs[it];
     // the last one (it == 0: msgs[0] = relu(input), no dropout) adds the dZ of every iteration -> d input
-    cur = c.ar.f(g.nB, H);
+    cur = c.alloc(g.nB, H);
     gather_epi(c, d_min, g.nB, g.b2b_t, g.nB, g.Kb, H, cur, st, partb, rr_linear_colsum_rows(g.nB), true, S.msgs[it], S.bits[it],
                it == 0 ? 1.0f : ks, dzs, it == 0 ? ndz : 0);
   }
@@ -523,16 +615,16 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
   const int H = m.H, depth = m.depth;
   const float ks = 1.0f / (1.0f - p);
   hipStream_t st = c.cur;
-  float* dz_o = c.ar.f(g.nA, H);
-  float* d_a = c.ar.f(g.nA, H);
-  float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
+  float* dz_o = c.alloc(g.nA, H);
+  float* d_a = c.alloc(g.nA, H);
+  float* part = c.alloc(rr_linear_colsum_rows(g.nA), r4(H));
   {
     rr_linear_args a = LA(g.nA, H);
     a.a1 = dH; a.lda1 = H; a.k1 = H; a.a_mask = S.h; a.a_mask_bits = S.bits_h; a.ld_mask = H; a.mask_scale = sign * ks;
     a.dz_out = dz_o; a.ld_dz = H; set_w(a, wo_t);
     a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
     a.c = d_a; a.ldc = H;
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
   }
   {
     rr_wgrad_args w = WA(g.nA, H, dz_o, H, G.wo, m.enc_wo.in, G.bo, accumulate);
@@ -541,7 +633,7 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
   }
   // per-copy W_h layers (it >= 1): gradients arrive masked from the gather that forms them (see mpn_backward); the one
   // that reaches the shared prefix stays unmasked - rr_gather_sum_masked_f32 masks it while summing over the copies
-  float* d_msg = c.ar.f(g.nB, H);
+  float* d_msg = c.alloc(g.nB, H);
   {
     const bool per_copy = depth - 2 >= 1;
     gather_epi(c, d_a, g.nA, g.b2t, g.nB, 1, H, d_msg, st, part, rr_linear_colsum_rows(g.nA), per_copy, S.msgs[depth - 1],
@@ -552,13 +644,13 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
   int wh_started = accumulate;
   for (int it = depth - 2; it >= 1; --it) {                                             // per-copy W_h layers
     float* dz = d_msg;
-    float* d_min = c.ar.f(g.nB, H);
-    float* partb = c.ar.f(rr_linear_colsum_rows(g.nB), r4(H));
+    float* d_min = c.alloc(g.nB, H);
+    float* partb = c.alloc(rr_linear_colsum_rows(g.nB), r4(H));
     rr_linear_args a = LA(g.nB, H);
     a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
     a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
     a.c = d_min; a.ldc = H;
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
     rr_wgrad_args w = WA(g.nB, H, dz, H, G.wh, H, G.bh, wh_started);
     w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x1_idx = g.b2a; w.x1_sub = S.msgs[it]; w.ldx1_sub = H; w.x1_sub_idx = g.b2revb;
     wgrad(c, w);
@@ -567,23 +659,23 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
       d_inp_full = dz;
       have_full = true;
     } else {
-      float* sum = c.ar.f(g.nB, H);                                                     // fresh buffer (side-stream readers)
+      float* sum = c.alloc(g.nB, H);                                                     // fresh buffer (side-stream readers)
       RR_TRY(c, rr_axpby_f32(1.0f, d_inp_full, 1.0f, dz, sum, g.nB * static_cast<int64_t>(H), st));
       d_inp_full = sum;
     }
-    d_msg = c.ar.f(g.nB, H);
+    d_msg = c.alloc(g.nB, H);
     gather_epi(c, d_min, g.nB, g.b2b_t, g.nB, g.Kb, H, d_msg, st, partb, rr_linear_colsum_rows(g.nB), it - 1 >= 1, S.msgs[it],
                S.bits[it], ks, nullptr, 0);
   }
   // ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
   // dz1 of every copy is read once, by the sum over the copies: mask and gather in one pass (no [nB, H] round trip), the
   // copies' masks re-derived from the dropout stream and z1_u instead of read back from msgs[1]
-  float* dz1_u = c.ar.f(gu.nB, H);
+  float* dz1_u = c.alloc(gu.nB, H);
   if (H % 4 == 0)
     RR_TRY(c, rr_gather_sum_dropmask_f32(d_msg, g.nB, H, S.z1_u, H, bmap_t, gu.nB, bmap_t_cols, H, p, S.seed0, ks, dz1_u, H, st));
   else
     RR_TRY(c, rr_gather_sum_masked_f32(d_msg, S.msgs[1], g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, ks, dz1_u, H, st));
-  float* d_inp_u = c.ar.f(gu.nB, H);
+  float* d_inp_u = c.alloc(gu.nB, H);
   if (have_full) {
     gather_sum(c, d_inp_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, d_inp_u, H, st);
     RR_TRY(c, rr_axpby_f32(1.0f, d_inp_u, 1.0f, dz1_u, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
@@ -595,14 +687,14 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     w.x1 = S.a0_u; w.ldx1 = H; w.k1 = H; w.x1_idx = gu.b2a; w.x1_sub = S.msg0_u; w.ldx1_sub = H; w.x1_sub_idx = gu.b2revb;
     wgrad(c, w);
   }
-  float* d_min_u = c.ar.f(gu.nB, H);
-  float* part_u = c.ar.f(rr_linear_colsum_rows(gu.nB), r4(H));
+  float* d_min_u = c.alloc(gu.nB, H);
+  float* part_u = c.alloc(rr_linear_colsum_rows(gu.nB), r4(H));
   {
     rr_linear_args a = LA(gu.nB, H);
     a.a1 = dz1_u; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
     a.colsum_w = gu.npad_b; a.colsum_partial = part_u; a.ld_partial = r4(H);
     a.c = d_min_u; a.ldc = H;
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
   }
   float* d_msg0_u = bond_adjoint(c, gu, H, d_min_u, part_u, st);
   RR_TRY(c, rr_relu_bwd_f32(d_msg0_u, S.msg0_u, 1.0f, nullptr, d_inp_u, gu.nB * static_cast<int64_t>(H), st));   // msg0 = relu(inp)
@@ -618,7 +710,7 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
   const int H = m.H, depth = m.diff_depth, FB = m.bond_fdim;
   const float ks = 1.0f / (1.0f - p);
   hipStream_t st = c.s.main;
-  float* d_hid = c.ar.f(g.nA, H);
+  float* d_hid = c.alloc(g.nA, H);
   float* d_x = nullptr;
   float* d_inp = nullptr;
   if (depth > 0) {
@@ -628,11 +720,11 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
     RR_TRY(c, rr_segment_mean_bwd_masked_f32(dvecs, ld_dvecs, g.a_scope, g.atom2mol, g.nA, H, F, p, out_seed, S.hid, H, S.bits_hid,
                                              ks, dz_o, H, st));
     const Packed wo_x = T.dif_wo_x, wo_a = T.dif_wo_a;
-    d_x = c.ar.f(g.nA, H);
+    d_x = c.alloc(g.nA, H);
     {
       rr_linear_args a = LA(g.nA, H);
       a.a1 = dz_o; a.lda1 = H; a.k1 = H; set_w(a, wo_x); a.c = d_x; a.ldc = H;
-      RR_TRY(c, rr_linear_f32(&a, st));
+      lin(c, a, st);
     }
     {
       rr_wgrad_args w = WA(g.nA, H, dz_o, H, G.w[RR_G_DIF_WO], 2 * H, G.b[RR_G_DIF_WO], 0);
@@ -640,18 +732,18 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
       w.x2 = S.a_last; w.ldx2 = H; w.k2 = H;
       wgrad(c, w);
     }
-    float* d_a = c.ar.f(g.nA, H);
-    float* part = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
+    float* d_a = c.alloc(g.nA, H);
+    float* part = c.alloc(rr_linear_colsum_rows(g.nA), r4(H));
     {
       rr_linear_args a = LA(g.nA, H);
       a.a1 = dz_o; a.lda1 = H; a.k1 = H;
       set_w(a, wo_a); a.colsum_w = g.npad; a.colsum_partial = part; a.ld_partial = r4(H);
       a.c = d_a; a.ldc = H;
-      RR_TRY(c, rr_linear_f32(&a, st));
+      lin(c, a, st);
     }
     const float* dzs[MAXD];
     int ndz = 0;
-    float* cur = c.ar.f(g.nA, H);
+    float* cur = c.alloc(g.nA, H);
     {
       const int top = depth - 1;
       gather_epi(c, d_a, g.nA, g.a2a_t, g.nA, g.K, H, cur, st, part, rr_linear_colsum_rows(g.nA), true, S.msgs[top], S.bits[top],
@@ -660,25 +752,25 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
     const Packed wh_t = T.dif_wh;
     for (int it = depth - 2; it >= 0; --it) {
       float* dz = cur;
-      float* d_a2 = c.ar.f(g.nA, H);
-      float* part2 = c.ar.f(rr_linear_colsum_rows(g.nA), r4(H));
+      float* d_a2 = c.alloc(g.nA, H);
+      float* part2 = c.alloc(rr_linear_colsum_rows(g.nA), r4(H));
       rr_linear_args a = LA(g.nA, H);
       a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
       a.colsum_w = g.npad; a.colsum_partial = part2; a.ld_partial = r4(H);
       a.c = d_a2; a.ldc = H;
-      RR_TRY(c, rr_linear_f32(&a, st));
+      lin(c, a, st);
       rr_wgrad_args w = WA(g.nA, H, dz, H, G.w[RR_G_DIF_WH], H + FB, G.b[RR_G_DIF_WH], it != depth - 2 ? 1 : 0);
       w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x2 = g.fb_sum; w.ldx2 = g.ld_fbs; w.k2 = FB;
       wgrad(c, w);
       dzs[ndz++] = dz;
-      cur = c.ar.f(g.nA, H);
+      cur = c.alloc(g.nA, H);
       gather_epi(c, d_a2, g.nA, g.a2a_t, g.nA, g.K, H, cur, st, part2, rr_linear_colsum_rows(g.nA), true, S.msgs[it], S.bits[it],
                  it == 0 ? 1.0f : ks, dzs, it == 0 ? ndz : 0);
     }
     d_inp = cur;
   } else {
     RR_TRY(c, rr_segment_mean_bwd_f32(dvecs, ld_dvecs, g.a_scope, g.atom2mol, g.nA, H, F, p, out_seed, d_hid, H, st));
-    d_inp = c.ar.f(g.nA, H);
+    d_inp = c.alloc(g.nA, H);
     RR_TRY(c, rr_relu_bwd_f32(d_hid, S.msgs[0], ks, d_inp, nullptr, g.nA * static_cast<int64_t>(H), st));   // hid = drop(relu(inp))
   }
   {
@@ -690,12 +782,12 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
   rr_linear_args a = LA(g.nA, H);
   a.a1 = d_inp; a.lda1 = H; a.k1 = H; set_w(a, wi_t);
   if (depth == 0) {
-    d_x = c.ar.f(g.nA, H);
+    d_x = c.alloc(g.nA, H);
   } else {
     a.residual = d_x; a.ldr = H;
   }
   a.c = d_x; a.ldc = H;
-  RR_TRY(c, rr_linear_f32(&a, st));
+  lin(c, a, st);
   return d_x;
 }
 
@@ -715,7 +807,7 @@ float* ffn_backward(Ctx& c, const rr_model& m, int64_t M, float p, const FfnSave
   const rr_linear_w& L = m.ffn[nl - 1];
   const float* d = dout;
   if (m.head != 0) {
-    float* draw = c.ar.f(M, L.out);
+    float* draw = c.alloc(M, L.out);
     RR_TRY(c, rr_head_bwd_f32(dout, S.raw, M, L.out, m.head, draw, st));
     d = draw;
   }
@@ -725,13 +817,13 @@ float* ffn_backward(Ctx& c, const rr_model& m, int64_t M, float p, const FfnSave
     wgrad(c, w);
   }
   const int ncur = ffn_dx_rows(m, nl - 1);
-  float* dx = c.ar.f(M, r4(ncur));
+  float* dx = c.alloc(M, r4(ncur));
   int64_t ld_dx = r4(ncur);
   {
     const Packed wt = T.ffn[nl - 1];
     rr_linear_args a = LA(M, ncur);
     a.a1 = d; a.lda1 = L.out; a.k1 = L.out; set_w(a, wt); a.c = dx; a.ldc = ld_dx;
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
   }
   for (int li = nl - 2; li >= 0; --li) {
     const rr_linear_w& Lh = m.ffn[li];
@@ -743,12 +835,12 @@ float* ffn_backward(Ctx& c, const rr_model& m, int64_t M, float p, const FfnSave
       wgrad(c, w);
     }
     const int nin = ffn_dx_rows(m, li);
-    float* dn = c.ar.f(M, r4(nin));
+    float* dn = c.alloc(M, r4(nin));
     const Packed wt = T.ffn[li];
     rr_linear_args a = LA(M, nin);
     a.a1 = dx; a.lda1 = ld_dx; a.k1 = Lh.out; a.a_mask = y; a.ld_mask = S.ld_hs[li + 1]; a.mask_scale = ks;
     set_w(a, wt); a.c = dn; a.ldc = r4(nin);
-    RR_TRY(c, rr_linear_f32(&a, st));
+    lin(c, a, st);
     dx = dn;
     ld_dx = r4(nin);
   }
@@ -765,7 +857,11 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
     pack_transposes(c, m, P.T, main);
     flush_packs(c, main);
   }
+  if (c.f16 && c.launch && c.status == RR_OK && c.amax_base != nullptr && c.namax < MAX_AMAX &&     // the backward's own slots
+      hipMemsetAsync(c.amax_base + c.namax, 0, (MAX_AMAX - c.namax) * sizeof(float), main) != hipSuccess)
+    c.fail(RR_ERR_LAUNCH);
   const PackedT& T = P.T;
+  c.reg(dout, s.p.M, m.ffn[m.n_ffn - 1].out, m.ffn[m.n_ffn - 1].out);   // (the FFN's weight gradients split too from 8192 molecules per step on)
   int64_t ld_dvecs = 0;
   float* dvecs = ffn_backward(c, m, s.p.M, p, P.f, dout, G, T, &ld_dvecs);
   const int32_t* xsi = s.mode == RR_STEP_DEDUP ? s.amap : nullptr;
@@ -773,7 +869,7 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
   // de-duplicated reactants: d r_h[u] = -(sum over the copies of atom u of d_diff) (fixed-order segment sum)
   const float* d_r = d_diff;
   if (s.mode == RR_STEP_DEDUP) {
-    float* t = c.ar.f(s.r.nA, H);
+    float* t = c.alloc(s.r.nA, H);
     gather_sum(c, d_diff, s.p.nA, H, s.amap_t, s.r.nA, s.amap_t_cols, H, t, H, main);
     d_r = t;
   }
@@ -788,6 +884,10 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
   // Only with the side stream: without it the weight gradients launch on c.cur, so the reactant pass on aux would
   // accumulate into buffers the product pass is still writing on main (no ordering between the two).
   const bool fork = c.aux_bwd && c.use_aux && c.use_side;
+  if (fork && c.split) {               // both passes read these bounds: found on main before the aux stream forks off
+    amax_of(c, d_diff, main);
+    amax_of(c, d_r, main);
+  }
   if (c.launch && fork) c.fail(stream_wait(c.s.aux, main));
   mpn_backward(c, m, s.p, P.pk, wh_t, wo_t, p, P.p, d_diff, 1.0f, E, 0);
   if (fork) c.cur = c.s.aux;
@@ -844,15 +944,17 @@ void rr_abi_plan_struct_sizes(size_t* graph, size_t* model, size_t* step, size_t
 size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
   if (check(model, step) != RR_OK) return 0;
   size_t need = 0;
-  for (int v = 0; v < 4; ++v) {                        // either GEMM path (RR_PLAN_F32_GEMM), with or without RR_PLAN_TRAIN, must fit
+  for (int v = 0; v < 6; ++v) {                        // every GEMM path (f32, three bf16 terms, two f16 terms), with or without RR_PLAN_TRAIN, must fit
     Ctx c;
     c.launch = false; c.status = RR_OK; c.ar.base = nullptr; c.ar.off = 0; c.ar.cap = 0; c.ar.overflow = false; c.npq = 0;
     c.use_side = c.use_aux = false;
     c.aux_bwd = false;
     c.cur = nullptr;
     c.s.main = c.s.side = c.s.aux = nullptr;
-    c.split = (v & 1) != 0;
-    c.train = (v & 2) != 0;
+    c.split = (v >> 1) != 0;
+    c.f16 = (v >> 1) == 2;
+    c.ntr = c.namax = 0; c.amax_base = nullptr;
+    c.train = (v & 1) != 0;
     Plan P;
     memset(&P, 0, sizeof(P));
     forward_all(c, *model, *step, P);
@@ -874,6 +976,8 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
   c.split = (flags & RR_PLAN_F32_GEMM) == 0;
+  c.f16 = c.split && (flags & RR_PLAN_F16X2_GEMM) != 0;
+  c.ntr = c.namax = 0; c.amax_base = nullptr;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
@@ -910,6 +1014,8 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
   c.split = (flags & RR_PLAN_F32_GEMM) == 0;
+  c.f16 = c.split && (flags & RR_PLAN_F16X2_GEMM) != 0;
+  c.ntr = c.namax = 0; c.amax_base = nullptr;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
@@ -941,6 +1047,8 @@ int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags,
   c.use_side = (flags & RR_PLAN_NO_SIDE_STREAM) == 0;
   c.use_aux = (flags & RR_PLAN_NO_AUX_STREAM) == 0;
   c.split = (flags & RR_PLAN_F32_GEMM) == 0;
+  c.f16 = c.split && (flags & RR_PLAN_F16X2_GEMM) != 0;
+  c.ntr = c.namax = 0; c.amax_base = nullptr;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   c.s.main = c.s.side = c.s.aux = nullptr;

@@ -211,10 +211,17 @@ def weighted_colsum(x, w, H: int, out, accumulate: bool):
     return out
 
 
+def amax(t, cols=None):
+    """max |t| over the first `cols` columns of a 2-D tensor as a device float (rr_amax_f32)"""
+    out = torch.zeros(1, dtype=torch.float32, device=t.device)
+    check(lib().rr_amax_f32(ptr(t), t.shape[0], int(t.shape[1] if cols is None else cols), _ld(t), ptr(out), stream()), "rr_amax_f32")
+    return out
+
+
 def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub_idx=None, a2=None, k2=0, a_mask=None,
            mask_scale=1.0, ldw=None, w_packed=False, bias=None, residual=None, act=ACT_NONE, drop_p=0.0, seed=0,
            out=None, c_pre=None, dz_out=None, dz_accumulate=False, residual_idx=None, colsum_w=None, mask_bits_out=None,
-           a_mask_bits=None, want_bits=False):
+           a_mask_bits=None, want_bits=False, amax_of=None):
     """One fused dense layer on the f32 MFMA (see rr_linear_args in include/reactranker_hip.h).
     colsum_w [M]: also returns the per-row-block partial sums of colsum_w[m] * out[m, :]  ->  (out, partial)."""
     ref = a1 if a1 is not None else a2
@@ -231,8 +238,11 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
     A.a_mask, A.ld_mask, A.mask_scale = ptr(a_mask), _ld(a_mask), float(mask_scale)
     A.dz_out, A.ld_dz, A.dz_accumulate = ptr(dz_out), _ld(dz_out), int(dz_accumulate)
     if w.dtype == torch.uint8:                          # LinW.pk / pk_t handed out the three-bf16-term images
-        w_packed, ldw = 2, 0
+        w_packed, ldw = (3 if getattr(w, "_rr_f16", False) else 2), 0   # (3: two f16 terms)
     A.w, A.ldw, A.w_packed = ptr(w), (w.stride(0) if ldw is None else ldw), int(w_packed)
+    if int(w_packed) == 3:                              # operand bounds of the two-f16-term form (the step plans keep theirs in the workspace)
+        bounds = amax_of if amax_of is not None else [amax(t, k) if t is not None else None for t, k in ((a1, k1), (a1_sub, k1), (a2, k2))]
+        A.a1_amax, A.a1_sub_amax, A.a2_amax = ptr(bounds[0]), ptr(bounds[1]), ptr(bounds[2])
     A.bias = ptr(bias)
     A.residual, A.ldr, A.residual_idx = ptr(residual), _ld(residual), ptr(residual_idx)
     A.act, A.drop_p, A.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -315,7 +325,7 @@ SPLIT_MIN_ROWS = 8192      # GEMMs over fewer rows (the FFN head: one row per mo
 
 
 def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=None, k1=0, x1_idx=None, x1_sub=None,
-          x1_sub_idx=None, x2=None, k2=0, accumulate=False, ld_dw=None, side=False):
+          x1_sub_idx=None, x2=None, k2=0, accumulate=False, ld_dw=None, side=False, amax_of=None):
     """dw (+)= dZ^T [X1|X2], dbias (+)= colsum(dZ) with dZ = dy * (mask > 0) * mask_scale.
     side=True (the model's backward passes) launches on the weight-gradient stream; the caller must
     SideStream.join() before anything reads dw/dbias."""
@@ -329,12 +339,12 @@ def wgrad(M: int, N: int, dy, dw, *, dbias=None, mask=None, mask_scale=1.0, x1=N
                     t.record_stream(side)
             with torch.cuda.stream(side):
                 return _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub, x1_sub_idx, x2, k2,
-                                     accumulate, ld_dw)
+                                     accumulate, ld_dw, amax_of)
     return _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub, x1_sub_idx, x2, k2, accumulate,
-                         ld_dw)
+                         ld_dw, amax_of)
 
 
-def _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub, x1_sub_idx, x2, k2, accumulate, ld_dw):
+def _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub, x1_sub_idx, x2, k2, accumulate, ld_dw, amax_of=None):
     K = k1 + k2
     nbytes = lib().rr_linear_wgrad_workspace_bytes(M, N, K)
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dy.device)
@@ -351,6 +361,9 @@ def _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub,
     A.workspace, A.workspace_bytes = ptr(ws), nbytes
     A.split = int(SplitGemm.enabled and M >= SPLIT_MIN_ROWS and N % 4 == 0 and
                   all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in (dy, mask, x1, x1_sub, x2)))
+    if A.split and amax_of is not None:                 # two f16 terms: bounds of (dy, x1, x1_sub, x2) as device floats (amax())
+        A.split = 2
+        A.dy_amax, A.x1_amax, A.x1_sub_amax, A.x2_amax = (ptr(t) for t in amax_of)
     # the event pair spans the main kernel and its ~12 us fixed-order reduce kernel
     kext = ((k1 + 3) & ~3) + k2 + 1                     # same k-block choice as rr_linear_wgrad_f32 (96 / 128 / 160 columns)
     nblk = (kext + 159) // 160
@@ -457,8 +470,11 @@ def _grad_like(t):
 class SplitGemm:
     """Encoder GEMMs on the bf16 matrix core: every f32 operand is written exactly as three bf16 terms and six
     products are accumulated in f32 (rr_linear_args.w_packed = 2; error at or below the f32 MFMA chain's).
-    enabled = False keeps every GEMM on v_mfma_f32_16x16x4_f32."""
+    enabled = False keeps every GEMM on v_mfma_f32_16x16x4_f32.
+    f16 = True (whole-step plans only): two f16 terms per operand instead (w_packed = 3, RR_PLAN_F16X2_GEMM): three products,
+    22 significant bits per operand, measured error at the f32 MFMA chain's level."""
     enabled = True
+    f16 = os.environ.get("RR_F16X2", "0") not in ("", "0")
 
 
 class LinW:
@@ -1028,7 +1044,8 @@ class StepPlan:
     def flags(train: bool = False) -> int:
         return ((0 if SideStream.enabled else _lib.RR_PLAN_NO_SIDE_STREAM) | (0 if AuxStream.enabled else _lib.RR_PLAN_NO_AUX_STREAM) |
                 (0 if SplitGemm.enabled else _lib.RR_PLAN_F32_GEMM) | (_lib.RR_PLAN_AUX_BACKWARD if AuxStream.backward else 0) |
-                (_lib.RR_PLAN_TRAIN if (train and not os.environ.get("RR_NO_TRAIN_PACK")) else 0))
+                (_lib.RR_PLAN_TRAIN if (train and not os.environ.get("RR_NO_TRAIN_PACK")) else 0) |
+                (_lib.RR_PLAN_F16X2_GEMM if (SplitGemm.enabled and SplitGemm.f16) else 0))
 
 
 class ReactionModelFn(torch.autograd.Function):

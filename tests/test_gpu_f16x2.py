@@ -1,0 +1,220 @@
+"""The two-f16-term GEMM path (rr_linear_args.w_packed = 3, rr_wgrad_args.split = 2, RR_PLAN_F16X2_GEMM): every operand is
+scaled by a power of two from a bound of its tensor's largest magnitude and written as two f16 terms (22 significant bits),
+three v_mfma_f32_16x16x32_f16 per k-step instead of six bf16 ones.  Checked here against f64 on operands of very different
+magnitudes (the scaling must keep the terms inside f16's 5 exponent bits), for every kernel geometry and operand form, plus
+the magnitude outputs that spare the next GEMM a pass over its operand (c_amax_out, dz_amax_out, rr_gather_epi.amax_out).
+Model-level parity of this path against the oracle: tests/conftest.py runs the model / trainer / headline modules in both modes."""
+import ctypes as C
+
+import pytest
+import torch
+
+from reactranker_amd import _lib
+from reactranker_amd import functions as Fn
+from reactranker_amd._lib import PackDesc, check, lib, ptr, stream
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+def _pack(w, transpose, rows, c0, k1, k2, kind):
+    dst = torch.empty(int(lib().rr_split_weight_bytes(rows, k1, k2)), dtype=torch.uint8, device=dev)
+    d = (PackDesc * 1)()
+    d[0].src, d[0].ld_src, d[0].transpose, d[0].rows, d[0].c0, d[0].k1, d[0].k2 = w.data_ptr(), w.stride(0), transpose, rows, c0, k1, k2
+    d[0].dst, d[0].split = dst.data_ptr(), kind
+    check(lib().rr_pack_weights_f32(d, 1, stream()), "pack")
+    if kind == 2:
+        dst._rr_f16 = True
+    return dst
+
+
+def _rel(out, ref, den):
+    return float(((out.double() - ref).abs() / den).max())
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(1, 4, 4), (1000, 300, 300), (777, 83, 84), (513, 61, 64), (300, 7, 9), (70001, 300, 304)])
+def test_amax_matches_torch(rows, cols, ld):
+    torch.manual_seed(rows)
+    x = torch.randn(rows, ld, device=dev) * torch.exp(3 * torch.randn(rows, 1, device=dev))
+    x[:, cols:] = 1e30                                   # padding columns must not count
+    x[rows // 2, cols // 2] = float("nan")               # NaNs are skipped
+    out = torch.zeros(1, device=dev)
+    check(lib().rr_amax_f32(ptr(x), rows, cols, ld, ptr(out), stream()), "amax")
+    ref = torch.nan_to_num(x[:, :cols], nan=0.0).abs().max()
+    assert float(out) == float(ref)
+    out.fill_(float(ref) * 2)                            # a maximum INTO the slot
+    check(lib().rr_amax_f32(ptr(x), rows, cols, ld, ptr(out), stream()), "amax")
+    assert float(out) == float(ref) * 2
+
+
+# (M, N, K1, K2): <4,4,8>, <10,10,8>, <19,5,8> (few rows), <19,19,12> one block per workgroup, persistent, <38,19,12>
+SHAPES = [(999, 32, 32, 0), (5000, 128, 128, 40), (4133, 300, 300, 0), (20011, 300, 61, 300), (60000, 300, 300, 0), (9001, 600, 600, 83)]
+
+
+@pytest.mark.parametrize("M,N,K1,K2", SHAPES)
+@pytest.mark.parametrize("xscale,wscale", [(1.0, 1.0), (1e-7, 30.0), (3e4, 1e-3)])
+def test_linear_f16x2_against_f64(M, N, K1, K2, xscale, wscale, parity_log):
+    torch.manual_seed(M + N)
+    K = K1 + K2
+    W = torch.randn(N, K, device=dev) / K ** 0.5 * wscale
+    b = torch.randn(N, device=dev) * xscale * wscale
+    # rows of very different magnitude inside one tensor (gradient-like): the scale follows the largest
+    x1 = torch.randn(M, (K1 + 3) // 4 * 4, device=dev) * torch.exp(2 * torch.randn(M, 1, device=dev)) * xscale
+    x2 = torch.randn(M, (K2 + 3) // 4 * 4, device=dev) * xscale * 0.3 if K2 else None
+    wh, wb = _pack(W, 0, N, 0, K1, K2, 2), _pack(W, 0, N, 0, K1, K2, 1)
+    cam = torch.zeros(1, device=dev)
+    o3 = torch.empty(M, N, device=dev)
+    A = Fn.linear                                        # (the wrapper computes the operand bounds with rr_amax_f32)
+    kw = dict(a1=x1, k1=K1, bias=b)
+    if K2:
+        kw.update(a2=x2, k2=K2)
+    o2 = A(M, N, wb, **kw)
+    A(M, N, wh, out=o3, **kw)
+    X = torch.cat([x1[:, :K1], x2[:, :K2]], 1) if K2 else x1[:, :K1]
+    ref = X.double() @ W.double().t() + b.double()
+    den = X.double().abs() @ W.double().abs().t() + b.double().abs() + 1e-300
+    # the two-term form's contract: 22 bits of every element within 2^-18 of its TENSOR's largest, an absolute error below
+    # 2^-40 of that largest otherwise - rows far below the largest row keep fewer bits (the three-term bf16 form keeps all)
+    floor = 2.0 ** -36 * float(X.abs().max()) * W.double().abs().sum(1)[None, :]
+    big = (X.abs().amax(1) >= 2.0 ** -14 * X.abs().max())
+    e2, e3 = _rel(o2, ref, den), _rel(o3, ref, den + 1e6 * floor)
+    e3_big = _rel(o3[big], ref[big], den[big])
+    parity_log(f"M {M} N {N} K {K1}+{K2} scales {xscale:g}/{wscale:g}: max err / sum|x||w|  bf16x3 {e2:.2e}  f16x2 {e3_big:.2e} "
+               f"(rows within 2^-14 of the largest: {int(big.sum())} of {M}); all rows, against sum|x||w| + 2^-16 max|x| sum|w|: {e3:.2e}")
+    assert e3_big <= 1e-6 and e3 <= 1e-6, (e2, e3_big, e3)
+
+
+def test_linear_f16x2_operand_forms_and_magnitude_outputs(parity_log):
+    """gathered operand minus gathered subtrahend with residual / ReLU / dropout; the masked dX form with its dZ side output,
+    sign-bit mask and column sums; c_amax_out / dz_amax_out equal the stored tensors' largest magnitudes"""
+    torch.manual_seed(3)
+    H, M = 300, 30011
+    nA = M // 2 + 3
+    W = torch.randn(H, H, device=dev) / 17
+    b = torch.randn(H, device=dev)
+    am = torch.randn(nA, H, device=dev) * 40
+    msg = torch.relu(torch.randn(M, H, device=dev)) * 40
+    inp = torch.randn(M, H, device=dev)
+    b2a = torch.randint(0, nA, (M,), device=dev, dtype=torch.int32)
+    rev = torch.randint(0, M, (M,), device=dev, dtype=torch.int32)
+    b2a[0] = -1
+    rev[0] = -1
+    wh = _pack(W, 0, H, 0, H, 0, 2)
+    A = _lib.LinearArgs()
+    out = torch.empty(M, H, device=dev)
+    bits = torch.empty(M, int(lib().rr_mask_bits_row_bytes(H)), dtype=torch.uint8, device=dev)
+    slots = torch.zeros(8, device=dev)
+    a_am, a_msg = Fn.amax(am), Fn.amax(msg)
+    A.M, A.N = M, H
+    A.a1, A.lda1, A.k1, A.a1_idx = ptr(am), H, H, ptr(b2a)
+    A.a1_sub, A.lda1_sub, A.a1_sub_idx = ptr(msg), H, ptr(rev)
+    A.mask_scale = 1.0
+    A.w, A.ldw, A.w_packed = ptr(wh), 0, 3
+    A.bias, A.residual, A.ldr, A.act = ptr(b), ptr(inp), H, Fn.ACT_RELU
+    A.drop_p, A.drop_seed = 0.1, 77
+    A.c, A.ldc = ptr(out), H
+    A.mask_bits_out = ptr(bits)
+    A.a1_amax, A.a1_sub_amax = ptr(a_am), ptr(a_msg)
+    A.c_amax_out = ptr(slots[0:1])
+    check(lib().rr_linear_f32(C.byref(A), stream()), "linear")
+    z = torch.zeros(1, device=dev)
+    X = torch.where(b2a[:, None] >= 0, am[b2a.clamp(min=0).long()], z) - torch.where(rev[:, None] >= 0, msg[rev.clamp(min=0).long()], z)
+    pre = X.double() @ W.double().t() + b.double() + inp.double()
+    den = X.double().abs() @ W.double().abs().t() + 1
+    ref = torch.where(out != 0, torch.relu(pre) / 0.9, torch.zeros_like(pre))
+    e = _rel(out, ref, den)
+    kept = float((out != 0).double().mean())
+    assert e <= 1e-6 and 0.35 < kept < 0.55, (e, kept)
+    assert float(slots[0]) == float(out.abs().max())
+    # masked dX: dz = dy * (out > 0) / 0.9 from the sign bits, dX = dz W, dz stored, weighted column sums
+    dy = torch.randn(M, H, device=dev) * 1e-6
+    wt = _pack(W, 1, H, 0, H, 0, 2)
+    dx = torch.empty(M, H, device=dev)
+    dz = torch.empty(M, H, device=dev)
+    cw = torch.rand(M, device=dev)
+    part = torch.empty(int(lib().rr_linear_colsum_rows(M)), H, device=dev)
+    a_dy = Fn.amax(dy)
+    B = _lib.LinearArgs()
+    B.M, B.N = M, H
+    B.a1, B.lda1, B.k1 = ptr(dy), H, H
+    B.a_mask, B.ld_mask, B.mask_scale, B.a_mask_bits = ptr(out), H, 1.0 / 0.9, ptr(bits)
+    B.dz_out, B.ld_dz = ptr(dz), H
+    B.w, B.ldw, B.w_packed = ptr(wt), 0, 3
+    B.c, B.ldc = ptr(dx), H
+    B.colsum_w, B.colsum_partial, B.ld_partial = ptr(cw), ptr(part), H
+    B.a1_amax = ptr(a_dy)
+    B.c_amax_out, B.dz_amax_out = ptr(slots[1:2]), ptr(slots[2:3])
+    check(lib().rr_linear_f32(C.byref(B), stream()), "linear dX")
+    dzr = torch.where(out > 0, dy * (1.0 / 0.9), torch.zeros_like(dy))
+    assert torch.equal(dz, dzr)
+    ref = dzr.double() @ W.double()
+    den = dzr.double().abs() @ W.double().abs() + 1e-300
+    e2 = _rel(dx, ref, den)
+    cs = (dx.double() * cw.double()[:, None]).sum(0)
+    ecs = float((part.double().sum(0) - cs).abs().max() / cs.abs().max())
+    parity_log(f"gathered forward max err {e:.2e}; masked dX (|dy| ~ 1e-6) max err {e2:.2e}; column sums {ecs:.2e}")
+    assert e2 <= 1e-6 and ecs <= 1e-5
+    assert float(slots[1]) == float(dx.abs().max()) and float(slots[2]) == float(dz.abs().max())
+
+
+@pytest.mark.parametrize("M", [9000, 70001])
+@pytest.mark.parametrize("zscale", [1.0, 1e-8])
+def test_wgrad_f16x2_against_f64(M, zscale, parity_log):
+    torch.manual_seed(M)
+    H = 300
+    nA = M // 2 + 5
+    am = torch.randn(nA, H, device=dev)
+    msg = torch.relu(torch.randn(M, H, device=dev))
+    dz = torch.randn(M, H, device=dev) * torch.exp(2 * torch.randn(M, 1, device=dev)) * zscale
+    b2a = torch.randint(0, nA, (M,), device=dev, dtype=torch.int32)
+    rev = torch.randint(0, M, (M,), device=dev, dtype=torch.int32)
+    z = torch.zeros(1, device=dev)
+    X = am[b2a.long()] - msg[rev.long()]
+    cases = [("W_h gather-sub", dict(x1=am, k1=H, x1_idx=b2a, x1_sub=msg, x1_sub_idx=rev), X, dz, None, 1.0)]
+    fa = torch.zeros(M, 64, device=dev)
+    fa[:, :61] = (torch.rand(M, 61, device=dev) < 0.1).float()
+    a2 = torch.randn(M, H, device=dev) * 100
+    y = torch.relu(torch.randn(M, H, device=dev))
+    cases.append(("W_o 61|300 masked", dict(x1=fa, k1=61, x2=a2, k2=H, mask=y, mask_scale=1.25), torch.cat([fa[:, :61], a2], 1),
+                  torch.where(y > 0, dz * 1.25, torch.zeros_like(dz)), y, 1.25))
+    for name, kw, Xr, dzr, _, _ in cases:
+        K = Xr.shape[1]
+        outs = []
+        for f16 in (False, True):
+            dw = torch.zeros(H, K, device=dev)
+            db = torch.zeros(H, device=dev)
+            bounds = [Fn.amax(dz), Fn.amax(kw["x1"], kw["k1"]), Fn.amax(kw["x1_sub"]) if "x1_sub" in kw else None,
+                      Fn.amax(kw["x2"]) if "x2" in kw else None] if f16 else None
+            Fn.wgrad(M, H, dz, dw, dbias=db, amax_of=bounds, **kw)
+            outs.append((dw, db))
+        ref = dzr.double().t() @ Xr.double()
+        den = dzr.double().abs().t() @ Xr.double().abs() + 1e-300
+        rb = dzr.double().sum(0)
+        dbn = dzr.double().abs().sum(0) + 1e-300
+        e = [(_rel(w, ref, den), _rel(b_, rb, dbn)) for w, b_ in outs]
+        parity_log(f"M {M} {name} |dz| x {zscale:g}: dW max err bf16x3 {e[0][0]:.2e} f16x2 {e[1][0]:.2e}; dbias {e[0][1]:.2e} / {e[1][1]:.2e}")
+        assert e[1][0] <= 2e-6 and e[1][1] <= 2e-6, e
+
+
+def test_gather_magnitude_outputs():
+    torch.manual_seed(5)
+    H, nB, nA, K = 300, 20000, 9000, 4
+    src = torch.randn(nB, H, device=dev)
+    idx = torch.randint(-1, nB, (nA, K), device=dev, dtype=torch.int32)
+    out = torch.empty(nA, H, device=dev)
+    slot = torch.zeros(1, device=dev)
+    check(lib().rr_gather_sum_amax_f32(ptr(src), nB, H, ptr(idx), nA, K, H, None, 0, 0, ptr(out), H, ptr(slot), stream()), "gather")
+    ref = torch.where(idx[:, :, None] >= 0, src[idx.clamp(min=0).long()], torch.zeros(1, device=dev)).sum(1)
+    assert torch.allclose(out, ref, atol=1e-5) and float(slot) == float(out.abs().max())
+    # the fused-epilogue gather: mask, scale, addends, padding-row partials
+    y = torch.randn(nA, H, device=dev)
+    add = torch.randn(nA, H, device=dev) * 3
+    part = torch.randn(7, H, device=dev)
+    e = _lib.GatherEpi()
+    e.mask, e.ld_mask, e.mask_scale, e.n_adds, e.ld_add = ptr(y), H, 1.5, 1, H
+    e.adds[0] = add.data_ptr()
+    slot2 = torch.zeros(1, device=dev)
+    e.amax_out = ptr(slot2)
+    out2 = torch.empty(nA, H, device=dev)
+    check(lib().rr_gather_sum_epi_f32(ptr(src), nB, H, ptr(idx), nA, K, H, ptr(part), 7, H, C.byref(e), ptr(out2), H, stream()), "gather epi")
+    assert float(slot2) == float(out2.abs().max())

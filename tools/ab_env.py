@@ -14,6 +14,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench  # noqa: E402
+from reactranker_amd import functions as Fn  # noqa: E402
 
 
 def main():
@@ -37,6 +38,9 @@ def main():
                 os.environ.pop(k, None)
             for k in ks:
                 os.environ[k] = "1"
+            Fn.SplitGemm.f16 = "RR_F16X2" in ks            # (Python-side switches: plan flags)
+            Fn.SideStream.enabled = "NOSIDE" not in ks
+            Fn.AuxStream.enabled = "NOAUX" not in ks
             for i in range(4):
                 R.train_step(R.pool[i % len(R.pool)])
             secs, per, _ = R.timed(lambda i: R.pool[i % len(R.pool)], a.steps)

@@ -35,7 +35,12 @@ def run(name, M, N, K, ref_x, dz_ref, **kw):
             Fn.SplitGemm.enabled = en
             dw = torch.zeros(N, K, device=dev); db_ = torch.zeros(N, device=dev)
             us.append(t(lambda: Fn.wgrad(M, N, kw["dy"], dw, dbias=db_, **{k: v for k, v in kw.items() if k != "dy"})))
-        print(f"      time f32 {us[0]:.1f} us   split {us[1]:.1f} us", flush=True)
+        Fn.SplitGemm.enabled = True                      # two f16 terms (rr_wgrad_args.split = 2), bounds computed once outside the loop
+        am = [Fn.amax(kw[k], kw.get(c)) if kw.get(k) is not None else None for k, c in (("dy", None), ("x1", "k1"), ("x1_sub", "k1"), ("x2", "k2"))]
+        dw = torch.zeros(N, K, device=dev); db_ = torch.zeros(N, device=dev)
+        Fn.wgrad(M, N, kw["dy"], dw, dbias=db_, amax_of=am, **{k: v for k, v in kw.items() if k != "dy"})
+        u3 = t(lambda: Fn.wgrad(M, N, kw["dy"], dw, dbias=db_, amax_of=am, **{k: v for k, v in kw.items() if k != "dy"}))
+        print(f"      time f32 {us[0]:.1f} us   split {us[1]:.1f} us   f16x2 {u3:.1f} us   (f16x2 error: dW {err(dw, ref, den)}, dbias {err(db_, rb, db)})", flush=True)
 Fn.SPLIT_MIN_ROWS = 1
 for M in ((777, 9000) if quick else (9000, 138881, 71425)):
     z = torch.zeros(1, device=dev)
