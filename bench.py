@@ -41,7 +41,8 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
-SPLIT_PRODUCTS = 6                # bf16 MFMA products issued per f32 multiply on the split path
+SPLIT_PRODUCTS = 6                # bf16 MFMA products issued per f32 multiply on the three-term split path
+F16X2_PRODUCTS = 3                # f16 MFMA products per multiply on the two-term path (same 2.5 PF dense peak)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 PRESETS = {
@@ -237,6 +238,7 @@ def rank_time(key, t):
 def summarise(recs, traffic):
     """Per-kernel live timings (HIP events on the launch stream) -> (roofline of the dominant MFMA kernel,
     roofline of the gather kernel, table)."""
+    from reactranker_amd import functions as Fn
     roof, roof_g, ktable = None, None, {}
     if not recs:
         return roof, roof_g, ktable
@@ -273,13 +275,17 @@ def summarise(recs, traffic):
         if "split" in dom:
             # the GEMM issues 6 bf16 MFMA products per f32 multiply: roofline-model intensity = issued flops / algorithmic
             # bytes against the bf16 balance point decides the bound
-            issued = SPLIT_PRODUCTS * fl
+            prods = F16X2_PRODUCTS if Fn.SplitGemm.f16 else SPLIT_PRODUCTS
+            issued = prods * fl
             hbm_bound = issued / max(by, 1.0) < PEAK_BF16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
             mview = dict(f32_equivalent_tflops=round(ach, 2), frac_of_f32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                          issued_bf16_tflops=round(issued / secs / 1e12, 1),
                          frac_of_bf16_mfma_peak=round(issued / secs / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                         note="f32 result from three exact bf16 terms per operand, 6 bf16 MFMA products per multiply "
-                              "(v_mfma_f32_16x16x32_bf16); f32-equivalent = algorithmic 2MNK flops")
+                         products_per_multiply=prods,
+                         note=("f32 result from two f16 terms per operand (22 significant bits, scaled per tensor), 3 f16 MFMA "
+                               "products per multiply (v_mfma_f32_16x16x32_f16)" if Fn.SplitGemm.f16 else
+                               "f32 result from three exact bf16 terms per operand, 6 bf16 MFMA products per multiply "
+                               "(v_mfma_f32_16x16x32_bf16)") + "; f32-equivalent = algorithmic 2MNK flops")
             gbs = by / secs / 1e9
             hview = dict(algorithmic_gbs=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4))
             if hbm_bound:
@@ -628,10 +634,31 @@ def main():
             f32_path = dict(queries_per_s=round(world * n32 * cfg["queries"] / float(t32.item()), 2),
                             ms_per_step=round(float(t32.item()) / n32 * 1e3, 3), steps=n32, step_ms=step_stats(per32),
                             note="same model state, same steps, SplitGemm.enabled = False (RR_PLAN_F32_GEMM): every GEMM on "
-                                 "v_mfma_f32_16x16x4_f32; `value` above is the three-bf16-term path")
+                                 "v_mfma_f32_16x16x4_f32; `value` above is the " +
+                                 ("two-f16-term path" if Fn.SplitGemm.f16 else "three-bf16-term path"))
         finally:
             Fn.SplitGemm.enabled = True
         log(f"f32-MFMA path: {f32_path}")
+    # ---- ... and with three exact bf16 terms per operand (six products: every operand bit kept) where `value` runs two f16 terms
+    bf16x3_path = None
+    if not args.no_f32_path and Fn.SplitGemm.f16:
+        Fn.SplitGemm.f16 = False
+        try:
+            for i in range(3):
+                R.train_step(pool[i % len(pool)])
+            n3 = min(args.steps, 15)
+            s3, per3, _ = R.timed(cyc(args.warmup + args.steps), n3)
+            t3 = torch.tensor([s3], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+            bf16x3_path = dict(queries_per_s=round(world * n3 * cfg["queries"] / float(t3.item()), 2),
+                               ms_per_step=round(float(t3.item()) / n3 * 1e3, 3), steps=n3, step_ms=step_stats(per3),
+                               note="same model state, same steps, SplitGemm.f16 = False: encoder GEMMs and weight gradients on "
+                                    "three exact bf16 terms per operand (6 x v_mfma_f32_16x16x32_bf16 per k-step; rounds 2-4's "
+                                    "headline path); `value` above runs two f16 terms (3 x v_mfma_f32_16x16x32_f16)")
+        finally:
+            Fn.SplitGemm.f16 = True
+        log(f"three-bf16-term path: {bf16x3_path}")
 
     # ---- streamed epoch: the SAME training step fed from shard files on disk
     epoch = None
@@ -743,9 +770,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gemm_arithmetic": "f32 in / f32 out / f32 accumulate; encoder GEMMs (rows = atoms / bonds) multiply through three "
-                               "exact bf16 terms per operand on the bf16 matrix core - measured error against f64 at or below "
-                               "the f32 MFMA chain (tests/test_gpu_split.py); the FFN head stays on v_mfma_f32_16x16x4_f32",
+            "gemm_arithmetic": ("f32 in / f32 out / f32 accumulate; encoder GEMMs and weight gradients (rows = atoms / bonds) multiply "
+                                "through two f16 terms per operand, scaled per tensor by a power of two (22 significant bits; three "
+                                "v_mfma_f32_16x16x32_f16 per k-step) - measured error against f64 at the f32 MFMA chain's level "
+                                "(tests/test_gpu_f16x2.py), every parity test passes in this mode and in the three-exact-bf16-term mode "
+                                "(`bf16x3_path`: six products, no operand bit dropped); the FFN head stays on v_mfma_f32_16x16x4_f32"
+                                if Fn.SplitGemm.f16 else
+                                "f32 in / f32 out / f32 accumulate; encoder GEMMs (rows = atoms / bonds) multiply through three "
+                                "exact bf16 terms per operand on the bf16 matrix core - measured error against f64 at or below "
+                                "the f32 MFMA chain (tests/test_gpu_split.py); the FFN head stays on v_mfma_f32_16x16x4_f32"),
             "config": {"workload": f"{cfg['workload']}, {cfg['queries']}-query steps, D-MPNN depth={cfg['depth']} "
                                    f"hidden={cfg['hidden']}",
                        "preset": args.config,
@@ -758,7 +791,7 @@ def main():
             "step_ms": step_stats(per_ms),
             "roofline": roof, "roofline_gather": roof_g, "roofline_isolated": roof_iso,
             "roofline_gather_isolated": roof_g_iso, "cpu_baseline": cpu,
-            "f32_mfma_path": f32_path, "epoch_stream": epoch, "presets": presets or None, "dp": dp_info,
+            "f32_mfma_path": f32_path, "bf16x3_path": bf16x3_path, "epoch_stream": epoch, "presets": presets or None, "dp": dp_info,
             "kernels": ktable, "kernels_isolated": ktable_iso, "final_loss": round(loss_val, 6),
             "host_prep_s": {"synthetic_generation": round(R.t_gen, 2), "native_pack_and_upload": round(R.t_pack, 2)},
         }

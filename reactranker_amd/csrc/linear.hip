@@ -693,12 +693,14 @@ __host__ __device__ __forceinline__ int rr_f16_exp(float bound) {
 __device__ __forceinline__ float rr_amax4(float m, f32x4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
-// `seen` = the slot's value read EARLIER (before the stores whose magnitudes m collects): reading it here would wait for
-// every store issued before the read - loads and stores retire in issue order - and drain the store queue
-__device__ __forceinline__ void rr_amax_commit_wave(float m, float seen, float* out) {
+// A wave's maximum into a word of LDS (the workgroup's running maximum; the device float gets ONE atomic per workgroup at
+// the end of the kernel).  Nothing here touches global memory: a load of the slot at this point would be waited for with
+// vmcnt behind every store the epilogue has just issued - loads and stores retire in issue order - and drain the store
+// queue at each row block (measured: the GEMM twice as slow); an atomic per wave and block is 4,464 atomics on one address.
+__device__ __forceinline__ void rr_amax_commit_wave(float m, unsigned int* lds_word) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > seen) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(lds_word, __float_as_uint(m));
 }
 __device__ __forceinline__ float rr_pow2(int e) { return __uint_as_float(static_cast<uint32_t>(127 + e) << 23); }
 __device__ __forceinline__ void split_pair_h(float x, float y, float S, uint32_t& p0, uint32_t& p1) {
@@ -748,8 +750,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     float b1 = (a.a1_amax ? *a.a1_amax : 0.f) + (a.a1_sub_amax ? *a.a1_sub_amax : 0.f);
     if (MODE == 2 || MODE == 3) b1 *= fabsf(a.mask_scale);
     const float b2 = a.a2_amax ? *a.a2_amax : 0.f;
-    const int e = rr_f16_exp(fmaxf(b1, b2));
-    xs = rr_pow2(14 - e);
+    const float bound = fmaxf(b1, b2);
+    const int e = rr_f16_exp(bound);
+    xs = bound < 2.5e33f ? rr_pow2(14 - e) : __builtin_nanf("");   // an infinite / > 2^110 element: no scale fits, every output is NaN
     ixs = rr_pow2(e - 14);
     iws = 1.0f / a.w[static_cast<int64_t>(P.t1 + P.t2) * (SRC_PANEL / 4)];   // (a power of two: exact)
   }
@@ -781,6 +784,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // same order per element: bit-identical to the one-block form.  Rows are counted in groups of 16 (one wave's rows).
   constexpr bool CAN_PERSIST = MODE == 0 && WAVES == 12 && NT == NTP && EPI == 0;
   const bool persist = CAN_PERSIST && P.persist != 0;
+  // the workgroup's running maxima of |C| / |dz_out| (rr_linear_args.c_amax_out / dz_amax_out): two words behind everything else
+  unsigned int* const amx = reinterpret_cast<unsigned int*>(smem + PF_OFF + (CAN_PERSIST ? WAVES * 2048 : 0));
+  if (tid == 0) { amx[0] = 0u; amx[1] = 0u; }           // (the prologue's barrier orders this before any use)
   int64_t g_cur = static_cast<int64_t>(blockIdx.x) * WAVES;            // first 16-row group of the current block
   int64_t g_end = g_cur + WAVES;                                        // end of this workgroup's range
   if (persist) {
@@ -1180,9 +1186,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   const bool has_bias = a.bias != nullptr;
   const bool relu = a.act == RR_ACT_RELU;
   float c_am = 0.f;                                    // largest |C| this lane stored (rr_linear_args.c_amax_out)
-  float c_seen = 0.f, dz_seen = 0.f;                   // the magnitude slots as they are now, read ahead of the stores
-  if (a.c_amax_out != nullptr) c_seen = *reinterpret_cast<volatile const float*>(a.c_amax_out);
-  if ((MODE == 2 || MODE == 3) && a.dz_amax_out != nullptr) dz_seen = *reinterpret_cast<volatile const float*>(a.dz_amax_out);
   auto finish = [&](f32x4 v, int n) -> f32x4 {
     if (relu) {
 #pragma unroll
@@ -1389,9 +1392,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #pragma unroll
     for (int i = 0; i < 5; ++i) d[i] = mb[i];
   }
-  if (a.c_amax_out != nullptr) rr_amax_commit_wave(c_am, c_seen, a.c_amax_out);
+  if (a.c_amax_out != nullptr) rr_amax_commit_wave(c_am, amx);
   if ((MODE == 2 || MODE == 3) && a.dz_amax_out != nullptr && blockIdx.y == 0) {
-    rr_amax_commit_wave(dz_am, dz_seen, a.dz_amax_out);
+    rr_amax_commit_wave(dz_am, amx + 1);
     dz_am = 0.f;
   }
   if (cs_on) {                                         // one partial row per 64 rows (rr_linear_colsum_rows) = per 4 waves
@@ -1428,12 +1431,21 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = f32x4(0.f);
   }
+  if (a.c_amax_out != nullptr || a.dz_amax_out != nullptr) {          // (uniform) one atomic per workgroup and output
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int vc = amx[0], vd = amx[1];
+      if (a.c_amax_out != nullptr && vc != 0u) atomicMax(reinterpret_cast<unsigned int*>(a.c_amax_out), vc);
+      if (a.dz_amax_out != nullptr && vd != 0u) atomicMax(reinterpret_cast<unsigned int*>(a.dz_amax_out), vd);
+    }
+  }
 #ifdef RR_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   RR_STAMP(3);
 #endif
 }
 
+constexpr int PACK_SCALE_BLOCKS = 16;
 // weight terms of the split path: dst = [k-step][column tile][term 0..2][lane 0..63][8 bf16], the LDS image of a k-step
 __device__ __forceinline__ void split_one(float x, uint16_t& t0, uint16_t& t1, uint16_t& t2) {
   uint32_t p0, p1, p2;
@@ -1444,7 +1456,7 @@ __device__ __forceinline__ void split_one(float x, uint16_t& t0, uint16_t& t1, u
 }
 __host__ __device__ constexpr int split_nt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : (N <= 304 ? 19 : 38)); }
 
-__device__ __forceinline__ void pack_split_elem(const rr_pack_desc& q, int64_t e) {
+__device__ __forceinline__ void pack_split_elem(const rr_pack_desc& q, int64_t e, float S) {
   const int nt = split_nt(q.rows);
   const int t1 = r32(q.k1) / SK;
   const int el = static_cast<int>(e & 7), lane = static_cast<int>((e >> 3) & 63);
@@ -1461,9 +1473,8 @@ __device__ __forceinline__ void pack_split_elem(const rr_pack_desc& q, int64_t e
   float v = 0.f;
   if (lc >= 0 && n < q.rows)
     v = q.transpose ? q.src[static_cast<int64_t>(lc) * q.ld_src + q.c0 + n] : q.src[static_cast<int64_t>(n) * q.ld_src + q.c0 + lc];
-  if (q.split == 2) {                                  // two f16 terms of S * L (S: pack_scale_kernel, behind the last image)
-    const int64_t nblk = static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * nt;
-    v *= q.dst[nblk * 512];
+  if (q.split == 2) {                                  // two f16 terms of S * L (S from pack_scale_kernel's partial maxima)
+    v *= S;
     _Float16* d = reinterpret_cast<_Float16*>(q.dst) + blk * 2 * 512 + lane * 8 + el;
     const _Float16 h = static_cast<_Float16>(v);
     d[0] = h;
@@ -1474,9 +1485,10 @@ __device__ __forceinline__ void pack_split_elem(const rr_pack_desc& q, int64_t e
   split_one(v, d[0], d[512], d[1024]);
 }
 
-// split = 2: S of each weight (one workgroup per weight walks its rows x (k1 + k2) elements; <= 600 x 983)
+// split = 2: largest magnitude of each weight, as PACK_SCALE_BLOCKS partial maxima behind its last image (floats 4 .. of the
+// trailer; pack_split_kernel folds them into S = the power of two with 2^14 <= S max|L| < 2^15 and stores S at float 0)
 __global__ void __launch_bounds__(1024) pack_scale_kernel(const PackMany P) {
-  const rr_pack_desc& q = P.d[blockIdx.x];
+  const rr_pack_desc& q = P.d[blockIdx.y];
   if (q.split != 2) return;
   __shared__ float part[16];
   const int K = q.k1 + q.k2;
@@ -1487,12 +1499,13 @@ __global__ void __launch_bounds__(1024) pack_scale_kernel(const PackMany P) {
     return fabsf(q.transpose ? q.src[static_cast<int64_t>(lc) * q.ld_src + q.c0 + n] : q.src[static_cast<int64_t>(n) * q.ld_src + q.c0 + lc]);
   };
   float m4[4] = {0.f, 0.f, 0.f, 0.f};
-  int64_t e = threadIdx.x;
-  for (; e + 3 * 1024 < total; e += 4 * 1024) {
+  constexpr int64_t ST = 1024 * PACK_SCALE_BLOCKS;
+  int64_t e = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x;
+  for (; e + 3 * ST < total; e += 4 * ST) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) m4[u] = fmaxf(m4[u], val(e + u * 1024));
+    for (int u = 0; u < 4; ++u) m4[u] = fmaxf(m4[u], val(e + u * ST));
   }
-  for (; e < total; e += 1024) m4[0] = fmaxf(m4[0], val(e));
+  for (; e < total; e += ST) m4[0] = fmaxf(m4[0], val(e));
   float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -1502,7 +1515,7 @@ __global__ void __launch_bounds__(1024) pack_scale_kernel(const PackMany P) {
 #pragma unroll
     for (int i = 1; i < 16; ++i) m = fmaxf(m, part[i]);
     const int64_t nblk = static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * split_nt(q.rows);
-    q.dst[nblk * 512] = rr_pow2(14 - rr_f16_exp(m));
+    q.dst[nblk * 512 + 4 + blockIdx.x] = m;
   }
 }
 
@@ -1511,7 +1524,17 @@ __global__ void __launch_bounds__(256) pack_split_kernel(const PackMany P) {
   if (!q.split) return;
   const int64_t total = static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * split_nt(q.rows) * 512;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) pack_split_elem(q, e);
+  float S = 1.f;
+  if (q.split == 2) {                                  // fold pack_scale_kernel's partial maxima; thread 0 leaves S for the GEMM
+    const int64_t nblk = total / 512;
+    const float* part = q.dst + nblk * 512 + 4;
+    float m = part[0];
+#pragma unroll
+    for (int i = 1; i < PACK_SCALE_BLOCKS; ++i) m = fmaxf(m, part[i]);
+    S = rr_pow2(14 - rr_f16_exp(m));
+    if (blockIdx.x == 0 && threadIdx.x == 0) q.dst[nblk * 512] = S;
+  }
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) pack_split_elem(q, e, S);
 }
 
 // ======================================================================== weight gradient
@@ -1997,11 +2020,14 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradPara
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float zs = 1.f, xsc = 1.f, izs = 1.f, ixs = 1.f;     // F16: operand scales from the caller's bounds (uniform) and their inverses
   if (F16) {
-    const int ez = rr_f16_exp((a.dy_amax ? *a.dy_amax : 0.f) * (HAS_MASK ? fabsf(a.mask_scale) : 1.f));
+    const float bz = (a.dy_amax ? *a.dy_amax : 0.f) * (HAS_MASK ? fabsf(a.mask_scale) : 1.f);
+    const int ez = rr_f16_exp(bz);
     const float bx = fmaxf((a.x1_amax ? *a.x1_amax : 0.f) + (a.x1_sub_amax ? *a.x1_sub_amax : 0.f), a.x2_amax ? *a.x2_amax : 0.f);
     const int ex = rr_f16_exp(fmaxf(bx, 1.0f));         // (the ones column of the extended X)
     zs = rr_pow2(14 - ez); izs = rr_pow2(ez - 14);
     xsc = rr_pow2(14 - ex); ixs = rr_pow2(ex - 14);
+    if (!(bz < 2.5e33f)) zs = __builtin_nanf("");       // an infinite / > 2^110 element: no scale fits, the gradient is NaN
+    if (!(bx < 2.5e33f)) xsc = __builtin_nanf("");
   }
   const int nt = P.nblk_n * P.nblk_k;                   // XCD-aware mapping, see wgrad_fast_kernel
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -2452,7 +2478,7 @@ int launch_split_epi(const LinearParams& P, hipStream_t s) {
   constexpr int panel2 = 2 * NT * (F16 ? 2 : 3) * 1024, bn4 = 16 * NT * 4;
   constexpr bool can_persist = MODE == 0 && WAVES == 12 && NT == NTP && EPI == 0;
   constexpr int smem = (WAVES == 12 ? ((12 * 8 * 77 * 16 > panel2 ? 12 * 8 * 77 * 16 : panel2) + 13 * bn4) : panel2 + bn4) +
-                       (can_persist ? WAVES * 2048 : 0);       // + the persistent form's operand prefetch slots
+                       (can_persist ? WAVES * 2048 : 0) + 16;  // + the persistent form's operand prefetch slots + the two magnitude words
   // > 64 KiB of LDS has to be asked for once per kernel AND per device (the attribute lives with the device's code
   // object); atomics because two host threads may launch the same instantiation at once (setting it twice is harmless)
   static std::atomic<uint64_t> configured{0};          // bit d: done on device d (devices >= 64 set it every launch)
@@ -2650,7 +2676,7 @@ int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
   if (biggest_split > 0) {
     bool any_f16 = false;
     for (int i = 0; i < n; ++i) any_f16 = any_f16 || descs[i].split == 2;
-    if (any_f16) pack_scale_kernel<<<static_cast<unsigned>(n), 1024, 0, static_cast<hipStream_t>(stream)>>>(P);
+    if (any_f16) pack_scale_kernel<<<dim3(PACK_SCALE_BLOCKS, static_cast<unsigned>(n)), 1024, 0, static_cast<hipStream_t>(stream)>>>(P);
     dim3 grid(static_cast<unsigned>(rr_grid_for(biggest_split, 256, 64)), static_cast<unsigned>(n));
     pack_split_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
   }

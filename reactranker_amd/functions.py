@@ -257,7 +257,7 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
         a_mask_bits = getattr(a_mask, "_rr_bits", None)  # ... and read them instead of the f32 activation (same values)
     A.mask_bits_out, A.a_mask_bits = ptr(mask_bits_out), ptr(a_mask_bits)    # sign-bit images (split GEMM only)
     nt = 4 if N <= 64 else (10 if N <= 160 else 19)
-    if M <= 8192 and not (w.dtype == torch.uint8 or int(w_packed) == 2):
+    if M <= 8192 and not (w.dtype == torch.uint8 or int(w_packed) >= 2):
         nt = 4                                          # few rows: 64-column blocks (rr_linear_f32)
     mode = 3 if a_mask_bits is not None else (2 if a_mask is not None else (1 if a1_sub is not None else 0))
     kk = k1 + k2
@@ -269,7 +269,7 @@ def linear(M: int, N: int, w, *, a1=None, k1=0, a1_idx=None, a1_sub=None, a1_sub
         nbytes += M * mask_bits_out.shape[1]
     if dz_out is not None:                              # side output d_input (+)= dZ: one write, one read when accumulating
         nbytes += 4 * M * k1 * (2 if dz_accumulate else 1)
-    if int(w_packed) == 2:                              # the symbol rocprofv3 shows: <tiles packed, tiles per WG, mode, waves>
+    if int(w_packed) >= 2:                              # the symbol rocprofv3 shows: <tiles packed, tiles per WG, mode, waves>
         ntp = 38 if N > 304 else nt
         if nt == 19 and ntp == 19 and M <= 8192:
             key = f"linear_split_kernel<19,5,{mode},8>"   # few rows: column blocks of 5 tiles (rr_linear_f32)
@@ -361,7 +361,10 @@ def _wgrad_launch(M, N, dy, dw, dbias, mask, mask_scale, x1, k1, x1_idx, x1_sub,
     A.workspace, A.workspace_bytes = ptr(ws), nbytes
     A.split = int(SplitGemm.enabled and M >= SPLIT_MIN_ROWS and N % 4 == 0 and
                   all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in (dy, mask, x1, x1_sub, x2)))
-    if A.split and amax_of is not None:                 # two f16 terms: bounds of (dy, x1, x1_sub, x2) as device floats (amax())
+    if A.split and (amax_of is not None or SplitGemm.f16):   # two f16 terms: bounds of (dy, x1, x1_sub, x2) as device floats
+        if amax_of is None:                              # (the step plans get them from the producing kernels instead)
+            amax_of = [amax(dy), amax(x1, k1) if x1 is not None else None, amax(x1_sub, k1) if x1_sub is not None else None,
+                       amax(x2, k2) if x2 is not None else None]
         A.split = 2
         A.dy_amax, A.x1_amax, A.x1_sub_amax, A.x2_amax = (ptr(t) for t in amax_of)
     # the event pair spans the main kernel and its ~12 us fixed-order reduce kernel
@@ -471,10 +474,12 @@ class SplitGemm:
     """Encoder GEMMs on the bf16 matrix core: every f32 operand is written exactly as three bf16 terms and six
     products are accumulated in f32 (rr_linear_args.w_packed = 2; error at or below the f32 MFMA chain's).
     enabled = False keeps every GEMM on v_mfma_f32_16x16x4_f32.
-    f16 = True (whole-step plans only): two f16 terms per operand instead (w_packed = 3, RR_PLAN_F16X2_GEMM): three products,
-    22 significant bits per operand, measured error at the f32 MFMA chain's level."""
+    f16 = True (the default; RR_F16X2=0 in the environment turns it off): two f16 terms per operand instead (w_packed = 3,
+    RR_PLAN_F16X2_GEMM): three products, 22 significant bits per operand scaled to its tensor's largest magnitude, measured
+    error at the f32 MFMA chain's level.  The step plans take the operand bounds from the producing kernels; the per-op
+    mirror below finds them with one rr_amax_f32 pass per operand (slower: it exists for tests and per-kernel timing)."""
     enabled = True
-    f16 = os.environ.get("RR_F16X2", "0") not in ("", "0")
+    f16 = os.environ.get("RR_F16X2", "1") not in ("", "0")
 
 
 class LinW:
@@ -495,20 +500,22 @@ class LinW:
         else:
             dst = torch.empty(rows, int(lib().rr_packed_weight_ld(k1, k2)), dtype=torch.float32, device=self.w.device)
         d[0].src, d[0].ld_src, d[0].transpose, d[0].rows, d[0].c0, d[0].k1, d[0].k2 = ptr(self.w), self.w.stride(0), transpose, rows, c0, k1, k2
-        d[0].dst, d[0].split = ptr(dst), int(split)
+        d[0].dst, d[0].split = ptr(dst), (2 if SplitGemm.f16 else 1) if split else 0
         check(lib().rr_pack_weights_f32(d, 1, stream()), "rr_pack_weights_f32")
+        if split and SplitGemm.f16:
+            dst._rr_f16 = True                           # two f16 terms: linear() passes w_packed = 3 and the operand bounds
         return dst
 
     def pk(self, k1: int, k2: int = 0):
         """Packed copy of W = [W1 | W2] for the fast GEMM paths (rr_pack_weights_f32: zero-padded f32, or bf16 terms)."""
-        key = ("f", k1, k2, SplitGemm.enabled)
+        key = ("f", k1, k2, SplitGemm.enabled, SplitGemm.f16)
         if key not in self._t:
             self._t[key] = self._pack(0, self.w.shape[0], 0, k1, k2)
         return self._t[key]
 
     def pk_t(self, c0: int, c1: int):
         """Packed (W[:, c0:c1])^T — the weight operand of dX = dZ * W[:, c0:c1]."""
-        key = ("t", c0, c1, SplitGemm.enabled)
+        key = ("t", c0, c1, SplitGemm.enabled, SplitGemm.f16)
         if key not in self._t:
             self._t[key] = self._pack(1, c1 - c0, c0, self.w.shape[0], 0)
         return self._t[key]

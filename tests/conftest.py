@@ -19,6 +19,37 @@ def golden_dir():
     return GOLDEN
 
 
+# ---------------------------------------------------------------------------------------------- GEMM arithmetic of the step plans
+# The whole-step plans run their encoder GEMMs on two f16 terms per operand by default (functions.SplitGemm.f16: 22
+# significant bits, three matrix instructions per k-step) or on three exact bf16 terms (six).  The modules that compare the
+# HIP path with the oracle / the reference's vectors run in BOTH modes; the modules that compare two HIP paths bit for bit
+# (the per-op Python mirror and the C++ host example only know the three-term form) are pinned to it.
+BOTH_GEMM_MODES = {"test_gpu_model", "test_gpu_headline_kernels", "test_gpu_trainers", "test_gpu_api_parity"}
+BF16X3_ONLY = {"test_gpu_plan", "test_gpu_cxx_host", "test_gpu_dp_trainers", "test_gpu_split"}
+
+
+def pytest_generate_tests(metafunc):
+    mod = metafunc.module.__name__.rsplit(".", 1)[-1]
+    if mod in BOTH_GEMM_MODES and "gemm_mode" in metafunc.fixturenames:
+        metafunc.parametrize("gemm_mode", ["f16x2", "bf16x3"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def gemm_mode(request):
+    mod = request.module.__name__.rsplit(".", 1)[-1]
+    mode = getattr(request, "param", "bf16x3" if mod in BF16X3_ONLY else None)
+    if mode is None or request.node.get_closest_marker("gpu") is None:
+        yield mode
+        return
+    from reactranker_amd import functions as Fn
+    old = Fn.SplitGemm.f16
+    Fn.SplitGemm.f16 = mode == "f16x2"
+    try:
+        yield mode
+    finally:
+        Fn.SplitGemm.f16 = old
+
+
 # ---------------------------------------------------------------------------------------------- measured parity errors
 # Every `-m gpu` parity test reports what it MEASURED (not just that it stayed under its bound) through the `parity_log`
 # fixture; the lines are merged into gpurun_out/parity_errors.txt (one block per test id, the latest run wins) and the

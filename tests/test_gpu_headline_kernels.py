@@ -255,7 +255,7 @@ def test_train_mode_plan_path_above_8192_rows_against_fp64_oracle_h600_d6(parity
     _train_step_vs_fp64_oracle(cfg, 8, 64, "evidential", 0.1, 16, 24, seed=601, log=parity_log)
 
 
-def test_split_path_nonfinite_and_huge_operands_behave_as_documented():
+def test_split_path_nonfinite_and_huge_operands_behave_as_documented(gemm_mode):
     """the three-term split keeps every finite f32 operand exactly while bf16(x) is finite, i.e.
     |x| < 3.3962e38 (the midpoint between the largest bf16, 3.3895e38, and 2^128); what differs in kind from the f32
     chain is pinned here - an infinite operand gives NaN (inf - inf in the remainder) where the f32 MFMA gives +-inf, a
@@ -274,6 +274,21 @@ def test_split_path_nonfinite_and_huge_operands_behave_as_documented():
     x[15, 6] = 1e-40                                     # subnormal: flushed or kept, it is far below the result's ulp
     o32 = Fn.linear(M, H, w32f, w_packed=True, a1=x, k1=H)
     osp = Fn.linear(M, H, wspf, w_packed=True, a1=x, k1=H)
+    if gemm_mode == "f16x2":
+        # two f16 terms: the operand scale follows the TENSOR's largest magnitude, so an infinite (or > 2^110) element leaves
+        # no usable scale and every output is NaN - loudly, not a row of plausible zeros; a NaN element (which the magnitude
+        # pass skips) poisons its own row only, like everywhere else
+        assert torch.isnan(osp).all()
+        x[10, 7] = x[11, 8] = 1.0
+        x[13, 5] = x[14, 5] = 2.0
+        osp = Fn.linear(M, H, wspf, w_packed=True, a1=x, k1=H)
+        clean = torch.ones(M, dtype=torch.bool, device=dev)
+        clean[12] = False
+        assert torch.isnan(osp[12]).all() and torch.isfinite(osp[clean]).all()
+        ref = x[clean].double() @ W.double().t()
+        den = x[clean].double().abs() @ W.double().abs().t() + 1e-300
+        assert float(((osp[clean].double() - ref).abs() / den).max()) < 2e-6
+        return
     assert torch.isinf(o32[10]).all() and torch.isinf(o32[11]).all()            # the f32 chain: inf * w = +-inf
     assert torch.isnan(osp[10]).all() and torch.isnan(osp[11]).all()            # the split path: NaN
     assert torch.isnan(o32[12]).all() and torch.isnan(osp[12]).all()
