@@ -68,7 +68,7 @@ int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src,
                              const float* row0_partial, int64_t n_partial, int64_t ld_partial,
                              float* out, int64_t ld_out, rr_stream_t stream);
 /* Both of the above in one entry point (row0_partial may be NULL), plus an optional magnitude output:
- * *amax_out = max(*amax_out, max |out|) - see rr_gather_epi.amax_out. */
+ * max |out| maxed into the magnitude slot amax_out - see rr_gather_epi.amax_out. */
 int rr_gather_sum_amax_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
                            int H, const float* row0_partial, int64_t n_partial, int64_t ld_partial, float* out,
                            int64_t ld_out, float* amax_out, rr_stream_t stream);
@@ -115,7 +115,7 @@ typedef struct rr_gather_epi {
   float mask_scale;
   int n_adds;               int64_t ld_add;      /* every addend is [n_out, ld_add] */
   const float* adds[RR_MAX_GATHER_ADDS];
-  float* amax_out;          /* optional: *amax_out = max(*amax_out, max |out|) (device float, atomically: zero it first) - the
+  float* amax_out;          /* optional: max |out| maxed into this magnitude slot (RR_AMAX_FLOATS floats, see rr_amax_f32) - the
                                bound a two-f16-term GEMM needs of this result (rr_linear_args.a1_amax) without a pass over it */
 } rr_gather_epi;
 int rr_gather_sum_epi_f32(const float* src, int64_t n_src, int64_t ld_src,
@@ -238,12 +238,13 @@ typedef struct rr_linear_args {
   const uint8_t* a_mask_bits;                       /* alternative to a_mask (w_packed >= 2, k2 = 0, k1 % 4 == 0): such a bit
                                                        image over the k1 columns of A; a_mask is then not read */
   const float* a1_amax;                             /* w_packed = 3 only (required there for every operand present): DEVICE */
-  const float* a1_sub_amax;                         /* floats, each >= max |x| over the elements of a1 / a1_sub / a2 this call */
-  const float* a2_amax;                             /* can read (rr_amax_f32 computes one; a bound that is too large costs
-                                                       low-end precision, one that is too small overflows f16) */
-  float* c_amax_out;                                /* optional outputs (w_packed >= 2): *p = max(*p, max |C| stored) and the same */
-  float* dz_amax_out;                               /* for dz_out - the bound the NEXT GEMM needs of this one's result, without a
-                                                       pass over it (device floats, atomically maxed: zero them first) */
+  const float* a1_sub_amax;                         /* magnitude slots (RR_AMAX_FLOATS floats each, see rr_amax_f32) whose maximum */
+  const float* a2_amax;                             /* is >= max |x| over the elements of a1 / a1_sub / a2 this call can read (a
+                                                       bound that is too large costs low-end precision, one that is too small
+                                                       overflows f16) */
+  float* c_amax_out;                                /* optional outputs (w_packed >= 2): max |C| stored, and the same for dz_out, */
+  float* dz_amax_out;                               /* maxed into a magnitude slot - the bound the NEXT GEMM needs of this one's
+                                                       result without a pass over it (zero the slot first) */
 } rr_linear_args;
 
 int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream);
@@ -299,7 +300,7 @@ typedef struct rr_wgrad_args {
                                                        accuracy, see rr_pack_desc.split) where the geometry allows vector
                                                        loads (16-byte aligned rows, N % 4 == 0); the f32 path otherwise.
                                                        2: two-f16-term operands (rr_linear_args.w_packed = 3), which needs */
-  const float* dy_amax;                             /* ... DEVICE floats >= max |.| of dy, x1, x1_sub, x2 (as a1_amax above) */
+  const float* dy_amax;                             /* ... the magnitude slots of dy, x1, x1_sub, x2 (as rr_linear_args.a1_amax) */
   const float* x1_amax;
   const float* x1_sub_amax;
   const float* x2_amax;
@@ -308,8 +309,14 @@ typedef struct rr_wgrad_args {
 size_t rr_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int rr_linear_wgrad_f32(const rr_wgrad_args* args, rr_stream_t stream);
 
-/* *amax = max(*amax, max over the [rows, cols] block of |x[r * ld + c]|)   (device float, atomically: zero it first; NaN
- * elements are skipped).  The operand bounds of the two-f16-term GEMMs (rr_linear_args.a1_amax, rr_wgrad_args.dy_amax). */
+/* A magnitude slot: RR_AMAX_LANES floats RR_AMAX_STRIDE floats apart (RR_AMAX_FLOATS floats in all, device memory) whose
+ * MAXIMUM is the bound - a producer's workgroups max their values into different lanes, because atomics on one busy address
+ * serialise (~5 ns each).  Zero the RR_AMAX_FLOATS floats before the first producer; every kernel only ever raises them.
+ * rr_amax_f32: slot = max(slot, max over the [rows, cols] block of |x[r * ld + c]|)  (NaN elements are skipped).
+ * The operand bounds of the two-f16-term GEMMs (rr_linear_args.a1_amax, rr_wgrad_args.dy_amax). */
+#define RR_AMAX_LANES 16
+#define RR_AMAX_STRIDE 32
+#define RR_AMAX_FLOATS (RR_AMAX_LANES * RR_AMAX_STRIDE)
 int rr_amax_f32(const float* x, int64_t rows, int cols, int64_t ld, float* amax, rr_stream_t stream);
 
 /* ------------------------------------------------------------------ elementwise ---- */

@@ -211,6 +211,8 @@ class AdamTensor(C.Structure):
 
 
 RR_MAX_ADAM = 64
+RR_AMAX_LANES, RR_AMAX_STRIDE = 16, 32
+RR_AMAX_FLOATS = RR_AMAX_LANES * RR_AMAX_STRIDE
 ABI_VERSION = 7
 (RR_SAVED_R_MSG, RR_SAVED_R_H, RR_SAVED_P_MSG, RR_SAVED_P_H, RR_SAVED_D_MSG, RR_SAVED_D_HID, RR_SAVED_VECS, RR_SAVED_FFN_H,
  RR_SAVED_R_MSG0_U, RR_SAVED_R_Z1_U) = range(10)

@@ -97,20 +97,17 @@ __device__ __forceinline__ void gather_walk(const float* __restrict__ src, int64
 #endif
 
 // Largest stored magnitude of a launch, for the two-f16-term GEMM that reads the result (rr_linear_args.a1_amax): every
-// thread folds what it stores into a running maximum and the workgroup maxes it into a device float once - one atomic per
-// workgroup, and only while it can still raise the slot as the workgroup saw it WHEN IT STARTED (amax_seen: a stale value
-// costs an atomic, never a result).  Reading the slot at the end instead would be waited for behind the thread's last stores
-// (loads and stores retire in issue order): ~2 us of idle tail per workgroup, +12-15 % per launch (measured).
+// thread folds what it stores into a running maximum and the workgroup maxes it into its lane of the magnitude slot
+// (rr_amax_put) - one atomic per workgroup, fire and forget.  Measured on the way here (profiles/r04_experiments.txt item 10):
+// a single float per tensor costs +70-80 % per launch (8,192 atomics on one address, ~5 ns each); checking the float first so
+// that only record-breaking workgroups touch it does not help - read at the end, the load waits behind the thread's last
+// stores (+12-15 %: ~2 us of idle tail per workgroup); read earlier, 2,048 concurrent workgroups all see the same stale value;
+// read with a scalar glc load, the launch takes 3-4 times as long.
 __device__ __forceinline__ float amax_fold(float m, f32x4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
 __device__ __forceinline__ float amax_fold(float m, float v) { return fmaxf(m, fabsf(v)); }
-__device__ __forceinline__ float amax_seen(const float* out) {   // at kernel entry (uniform address: a scalar load)
-  float v = out != nullptr ? *out : 0.f;
-  asm volatile("" : "+r"(v));                                     // (materialised here, not sunk to its use after the stores)
-  return v;
-}
-__device__ inline void amax_commit(float m, float seen, float* out) {      // every thread of the workgroup calls it (out is uniform)
+__device__ inline void amax_commit(float m, float* out) {      // every thread of the workgroup calls it (out is uniform)
   if (out == nullptr) return;
   __shared__ float amax_part[4];
 #pragma unroll
@@ -118,8 +115,7 @@ __device__ inline void amax_commit(float m, float seen, float* out) {      // ev
   if ((threadIdx.x & 63) == 0) amax_part[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(amax_part[0], amax_part[1]), fmaxf(amax_part[2], amax_part[3]));
-    if (m > seen) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+    rr_amax_put(out, fmaxf(fmaxf(amax_part[0], amax_part[1]), fmaxf(amax_part[2], amax_part[3])));
   }
 }
 
@@ -220,7 +216,6 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
   using V = typename Vec<VEC>::T;
   const int64_t total = n_out * HV;
   float am = 0.f;
-  const float seen = amax_seen(amax_out);
   // With a padding-row reduction the LAST HV blocks of the grid do that instead of gathering: block j sums column
   // group j of all partial rows (256 threads stride over the rows, then a fixed-order LDS + shuffle tree) and writes
   // out[0, group j] - the reduction runs next to the gather instead of as a straggler thread or an extra launch.
@@ -250,7 +245,7 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
         am = amax_fold(am, v);
       }
     }
-    amax_commit(am, seen, amax_out);
+    amax_commit(am, amax_out);
     return;
   }
 #ifdef RR_GATHER_WALK
@@ -270,7 +265,7 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
       else if (K == 3) gather_walk<3>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else if (K == 2) gather_walk<2>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else gather_walk<1>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
-      amax_commit(am, seen, amax_out);
+      amax_commit(am, amax_out);
       return;
     }
   }
@@ -299,7 +294,7 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
     st<VEC>(out + r * ld_out + c, acc);
     am = amax_fold(am, acc);
   }
-  amax_commit(am, seen, amax_out);
+  amax_commit(am, amax_out);
 }
 
 // ------------------------------------------------------------------------ gather-sum with a fused epilogue
@@ -397,7 +392,6 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
   using V = f32x4;
   const int64_t total = n_out * HV;
   float am = 0.f;
-  const float seen = amax_seen(E.amax_out);
   const int gblocks = row0_partial ? static_cast<int>(gridDim.x) - HV : static_cast<int>(gridDim.x);
   if (row0_partial != nullptr && static_cast<int>(blockIdx.x) >= gblocks) {      // padding-row reduction, see gather_sum_kernel
     __shared__ float red[256 * 4];
@@ -421,7 +415,7 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
         am = amax_fold(am, o);
       }
     }
-    amax_commit(am, seen, E.amax_out);
+    amax_commit(am, E.amax_out);
     return;
   }
 #ifdef RR_GATHER_WALK
@@ -442,7 +436,7 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
       else if (K == 3) gather_walk<3>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else if (K == 2) gather_walk<2>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
       else gather_walk<1>(src, ld_src, idx, K, HV, wbeg, wend, pre, fin);
-      amax_commit(am, seen, E.amax_out);
+      amax_commit(am, E.amax_out);
       return;
     }
   }
@@ -470,7 +464,7 @@ __global__ void __launch_bounds__(256) gather_sum_epi_kernel(const float* __rest
     st<4>(out + r * ld_out + c, o);
     am = amax_fold(am, o);
   }
-  amax_commit(am, seen, E.amax_out);
+  amax_commit(am, E.amax_out);
 }
 
 // out[r] = sum_{j in [offs[r], offs[r+1])} src[idx[j]]  (CSR form: rows with arbitrarily many sources - the adjoint of a

@@ -747,9 +747,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // two-term f16 form: the operand scale from the caller's bounds (uniform: scalar loads), the weight's from its image
   float xs = 1.f, ixs = 1.f, iws = 1.f;
   if (F16) {
-    float b1 = (a.a1_amax ? *a.a1_amax : 0.f) + (a.a1_sub_amax ? *a.a1_sub_amax : 0.f);
+    float b1 = (a.a1_amax ? rr_amax_read(a.a1_amax) : 0.f) + (a.a1_sub_amax ? rr_amax_read(a.a1_sub_amax) : 0.f);
     if (MODE == 2 || MODE == 3) b1 *= fabsf(a.mask_scale);
-    const float b2 = a.a2_amax ? *a.a2_amax : 0.f;
+    const float b2 = a.a2_amax ? rr_amax_read(a.a2_amax) : 0.f;
     const float bound = fmaxf(b1, b2);
     const int e = rr_f16_exp(bound);
     xs = bound < 2.5e33f ? rr_pow2(14 - e) : __builtin_nanf("");   // an infinite / > 2^110 element: no scale fits, every output is NaN
@@ -1435,8 +1435,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned int vc = amx[0], vd = amx[1];
-      if (a.c_amax_out != nullptr && vc != 0u) atomicMax(reinterpret_cast<unsigned int*>(a.c_amax_out), vc);
-      if (a.dz_amax_out != nullptr && vd != 0u) atomicMax(reinterpret_cast<unsigned int*>(a.dz_amax_out), vd);
+      if (a.c_amax_out != nullptr) rr_amax_put(a.c_amax_out, __uint_as_float(vc));
+      if (a.dz_amax_out != nullptr) rr_amax_put(a.dz_amax_out, __uint_as_float(vd));
     }
   }
 #ifdef RR_TRACE
@@ -2020,9 +2020,10 @@ __global__ void __launch_bounds__(THREADS, 2) wgrad_split_kernel(const WgradPara
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float zs = 1.f, xsc = 1.f, izs = 1.f, ixs = 1.f;     // F16: operand scales from the caller's bounds (uniform) and their inverses
   if (F16) {
-    const float bz = (a.dy_amax ? *a.dy_amax : 0.f) * (HAS_MASK ? fabsf(a.mask_scale) : 1.f);
+    const float bz = (a.dy_amax ? rr_amax_read(a.dy_amax) : 0.f) * (HAS_MASK ? fabsf(a.mask_scale) : 1.f);
     const int ez = rr_f16_exp(bz);
-    const float bx = fmaxf((a.x1_amax ? *a.x1_amax : 0.f) + (a.x1_sub_amax ? *a.x1_sub_amax : 0.f), a.x2_amax ? *a.x2_amax : 0.f);
+    const float bx = fmaxf((a.x1_amax ? rr_amax_read(a.x1_amax) : 0.f) + (a.x1_sub_amax ? rr_amax_read(a.x1_sub_amax) : 0.f),
+                           a.x2_amax ? rr_amax_read(a.x2_amax) : 0.f);
     const int ex = rr_f16_exp(fmaxf(bx, 1.0f));         // (the ones column of the extended X)
     zs = rr_pow2(14 - ez); izs = rr_pow2(ez - 14);
     xsc = rr_pow2(14 - ex); ixs = rr_pow2(ex - 14);
@@ -2415,8 +2416,8 @@ __global__ void __launch_bounds__(256) linear_rowdot_kernel(const float* __restr
 }
 
 
-// largest magnitude of a [rows, per_row (x 4 when VEC)] block, atomically maxed into *out (non-negative floats order like
-// their bit patterns; a NaN fails every comparison and is skipped)
+// largest magnitude of a [rows, per_row (x 4 when VEC)] block, maxed into the magnitude slot `out` (non-negative floats order
+// like their bit patterns; a NaN fails every comparison and is skipped)
 template <bool VEC>
 __global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, int64_t total, int per_row, int64_t ld, int tail,
                                                    float* __restrict__ out) {
@@ -2461,9 +2462,7 @@ __global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, 
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = r;
   __syncthreads();
   if (threadIdx.x == 0) {
-    r = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    // one atomic per workgroup, and only while it can still raise the slot (a stale read costs an atomic, never a result)
-    if (r > *reinterpret_cast<volatile float*>(out)) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(r));
+    rr_amax_put(out, fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
   }
 }
 

@@ -81,7 +81,7 @@ int stream_wait(hipStream_t waiter, hipStream_t signaller) {
 struct Packed { const float* w; int64_t ld; int mode; };   // mode = rr_linear_args.w_packed (1 f32 layout, 2 bf16 terms)
 
 // Two-f16-term GEMMs (RR_PLAN_F16X2_GEMM) need an upper bound of every operand tensor's magnitude.  The plan keeps one
-// float per tensor in a block of the workspace (zeroed at the start of the forward / of the backward's own part), found
+// magnitude slot (RR_AMAX_FLOATS floats, include/reactranker_hip.h) per tensor in a block of the workspace (zeroed at the start of the forward / of the backward's own part), found
 // by one rr_amax_f32 pass on the stream of the tensor's FIRST consumer and shared by every later one (a forward
 // activation's slot serves its weight gradient in the backward: the workspace is kept).  Tensors are known by address:
 // every arena allocation and the step's input arrays are recorded with their shape.
@@ -136,7 +136,7 @@ const float* amax_of(Ctx& c, const float* t, hipStream_t st) {
     if (r.p != t) continue;
     if (r.amax == nullptr) {
       if (c.namax == MAX_AMAX) { c.fail(RR_ERR_UNSUPPORTED); return nullptr; }
-      r.amax = c.amax_base + c.namax++;
+      r.amax = c.amax_base + static_cast<size_t>(c.namax++) * RR_AMAX_FLOATS;
       RR_TRY(c, rr_amax_f32(r.p, r.rows, static_cast<int>(r.cols), r.ld, r.amax, st));
     }
     return r.amax;
@@ -154,7 +154,7 @@ float* amax_claim(Ctx& c, const float* t) {
     if (r.p != t) continue;
     if (r.amax == nullptr) {
       if (c.namax == MAX_AMAX) { c.fail(RR_ERR_UNSUPPORTED); return nullptr; }
-      r.amax = c.amax_base + c.namax++;
+      r.amax = c.amax_base + static_cast<size_t>(c.namax++) * RR_AMAX_FLOATS;
     }
     return r.amax;
   }
@@ -507,8 +507,8 @@ void forward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P) {
   c.namax = 0;
   c.amax_base = nullptr;
   if (c.f16) {
-    c.amax_base = c.ar.f(1, MAX_AMAX);
-    if (c.launch && c.status == RR_OK && hipMemsetAsync(c.amax_base, 0, MAX_AMAX * sizeof(float), main) != hipSuccess) c.fail(RR_ERR_LAUNCH);
+    c.amax_base = c.ar.f(MAX_AMAX, RR_AMAX_FLOATS);
+    if (c.launch && c.status == RR_OK && hipMemsetAsync(c.amax_base, 0, static_cast<size_t>(MAX_AMAX) * RR_AMAX_FLOATS * sizeof(float), main) != hipSuccess) c.fail(RR_ERR_LAUNCH);
     const rr_graph* gs[3] = {&s.p, &s.r, &s.u};
     for (int i = 0; i < (s.mode == RR_STEP_PREFIX ? 3 : 2); ++i) {
       const rr_graph& g = *gs[i];
@@ -858,7 +858,7 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
     flush_packs(c, main);
   }
   if (c.f16 && c.launch && c.status == RR_OK && c.amax_base != nullptr && c.namax < MAX_AMAX &&     // the backward's own slots
-      hipMemsetAsync(c.amax_base + c.namax, 0, (MAX_AMAX - c.namax) * sizeof(float), main) != hipSuccess)
+      hipMemsetAsync(c.amax_base + static_cast<size_t>(c.namax) * RR_AMAX_FLOATS, 0, static_cast<size_t>(MAX_AMAX - c.namax) * RR_AMAX_FLOATS * sizeof(float), main) != hipSuccess)
     c.fail(RR_ERR_LAUNCH);
   const PackedT& T = P.T;
   c.reg(dout, s.p.M, m.ffn[m.n_ffn - 1].out, m.ffn[m.n_ffn - 1].out);   // (the FFN's weight gradients split too from 8192 molecules per step on)

@@ -30,6 +30,22 @@ static inline int rr_launch_status() {
 }
 #endif
 
+// A magnitude slot (rr_linear_args.a1_amax, c_amax_out, rr_gather_epi.amax_out ...) is RR_AMAX_LANES floats RR_AMAX_STRIDE
+// floats apart - one 128-byte line each - and the bound is their maximum: a producer's workgroups max their values into lane
+// blockIdx.x % RR_AMAX_LANES, so a launch of 8,192 workgroups queues 512 atomics per address instead of 8,192 on one (an
+// atomic on a busy address costs ~5 ns: measured +70-80 % on a gather launch with a single float per tensor).
+#ifdef __HIPCC__
+__device__ __forceinline__ float rr_amax_read(const float* slot) {        // (uniform address: scalar loads)
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < RR_AMAX_LANES; ++i) m = fmaxf(m, slot[i * RR_AMAX_STRIDE]);
+  return m;
+}
+__device__ __forceinline__ void rr_amax_put(float* slot, float m) {       // one thread per workgroup
+  if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(slot + RR_AMAX_STRIDE * (blockIdx.x & (RR_AMAX_LANES - 1))), __float_as_uint(m));
+}
+#endif
+
 static inline bool rr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Grid cap of the grid-stride streaming kernels.  Every pass of such a loop ends in a store and starts with

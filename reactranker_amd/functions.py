@@ -212,8 +212,9 @@ def weighted_colsum(x, w, H: int, out, accumulate: bool):
 
 
 def amax(t, cols=None):
-    """max |t| over the first `cols` columns of a 2-D tensor as a device float (rr_amax_f32)"""
-    out = torch.zeros(1, dtype=torch.float32, device=t.device)
+    """max |t| over the first `cols` columns of a 2-D tensor as a magnitude slot (rr_amax_f32: RR_AMAX_FLOATS device floats
+    whose maximum is the bound; `float(slot.max())` reads it)"""
+    out = torch.zeros(_lib.RR_AMAX_FLOATS, dtype=torch.float32, device=t.device)
     check(lib().rr_amax_f32(ptr(t), t.shape[0], int(t.shape[1] if cols is None else cols), _ld(t), ptr(out), stream()), "rr_amax_f32")
     return out
 

@@ -38,13 +38,15 @@ def test_amax_matches_torch(rows, cols, ld):
     x = torch.randn(rows, ld, device=dev) * torch.exp(3 * torch.randn(rows, 1, device=dev))
     x[:, cols:] = 1e30                                   # padding columns must not count
     x[rows // 2, cols // 2] = float("nan")               # NaNs are skipped
-    out = torch.zeros(1, device=dev)
+    out = torch.zeros(_lib.RR_AMAX_FLOATS, device=dev)   # a magnitude slot: 16 lanes on separate cache lines, the bound is their maximum
     check(lib().rr_amax_f32(ptr(x), rows, cols, ld, ptr(out), stream()), "amax")
     ref = torch.nan_to_num(x[:, :cols], nan=0.0).abs().max()
-    assert float(out) == float(ref)
-    out.fill_(float(ref) * 2)                            # a maximum INTO the slot
+    assert float(out.max()) == float(ref)
+    lanes = out.view(_lib.RR_AMAX_LANES, _lib.RR_AMAX_STRIDE)
+    assert float(lanes[:, 1:].abs().max()) == 0.0        # only the lanes' first floats are written
+    out[0] = float(ref) * 2                              # a maximum INTO the slot
     check(lib().rr_amax_f32(ptr(x), rows, cols, ld, ptr(out), stream()), "amax")
-    assert float(out) == float(ref) * 2
+    assert float(out.max()) == float(ref) * 2
 
 
 # (M, N, K1, K2): <4,4,8>, <10,10,8>, <19,5,8> (few rows), <19,19,12> one block per workgroup, persistent, <38,19,12>
@@ -103,7 +105,7 @@ def test_linear_f16x2_operand_forms_and_magnitude_outputs(parity_log):
     A = _lib.LinearArgs()
     out = torch.empty(M, H, device=dev)
     bits = torch.empty(M, int(lib().rr_mask_bits_row_bytes(H)), dtype=torch.uint8, device=dev)
-    slots = torch.zeros(8, device=dev)
+    slots = torch.zeros(4, _lib.RR_AMAX_FLOATS, device=dev)
     a_am, a_msg = Fn.amax(am), Fn.amax(msg)
     A.M, A.N = M, H
     A.a1, A.lda1, A.k1, A.a1_idx = ptr(am), H, H, ptr(b2a)
@@ -115,7 +117,7 @@ def test_linear_f16x2_operand_forms_and_magnitude_outputs(parity_log):
     A.c, A.ldc = ptr(out), H
     A.mask_bits_out = ptr(bits)
     A.a1_amax, A.a1_sub_amax = ptr(a_am), ptr(a_msg)
-    A.c_amax_out = ptr(slots[0:1])
+    A.c_amax_out = ptr(slots[0])
     check(lib().rr_linear_f32(C.byref(A), stream()), "linear")
     z = torch.zeros(1, device=dev)
     X = torch.where(b2a[:, None] >= 0, am[b2a.clamp(min=0).long()], z) - torch.where(rev[:, None] >= 0, msg[rev.clamp(min=0).long()], z)
@@ -125,7 +127,7 @@ def test_linear_f16x2_operand_forms_and_magnitude_outputs(parity_log):
     e = _rel(out, ref, den)
     kept = float((out != 0).double().mean())
     assert e <= 1e-6 and 0.35 < kept < 0.55, (e, kept)
-    assert float(slots[0]) == float(out.abs().max())
+    assert float(slots[0].max()) == float(out.abs().max())
     # masked dX: dz = dy * (out > 0) / 0.9 from the sign bits, dX = dz W, dz stored, weighted column sums
     dy = torch.randn(M, H, device=dev) * 1e-6
     wt = _pack(W, 1, H, 0, H, 0, 2)
@@ -143,7 +145,7 @@ def test_linear_f16x2_operand_forms_and_magnitude_outputs(parity_log):
     B.c, B.ldc = ptr(dx), H
     B.colsum_w, B.colsum_partial, B.ld_partial = ptr(cw), ptr(part), H
     B.a1_amax = ptr(a_dy)
-    B.c_amax_out, B.dz_amax_out = ptr(slots[1:2]), ptr(slots[2:3])
+    B.c_amax_out, B.dz_amax_out = ptr(slots[1]), ptr(slots[2])
     check(lib().rr_linear_f32(C.byref(B), stream()), "linear dX")
     dzr = torch.where(out > 0, dy * (1.0 / 0.9), torch.zeros_like(dy))
     assert torch.equal(dz, dzr)
@@ -154,7 +156,7 @@ def test_linear_f16x2_operand_forms_and_magnitude_outputs(parity_log):
     ecs = float((part.double().sum(0) - cs).abs().max() / cs.abs().max())
     parity_log(f"gathered forward max err {e:.2e}; masked dX (|dy| ~ 1e-6) max err {e2:.2e}; column sums {ecs:.2e}")
     assert e2 <= 1e-6 and ecs <= 1e-5
-    assert float(slots[1]) == float(dx.abs().max()) and float(slots[2]) == float(dz.abs().max())
+    assert float(slots[1].max()) == float(dx.abs().max()) and float(slots[2].max()) == float(dz.abs().max())
 
 
 @pytest.mark.parametrize("M", [9000, 70001])
@@ -202,10 +204,10 @@ def test_gather_magnitude_outputs():
     src = torch.randn(nB, H, device=dev)
     idx = torch.randint(-1, nB, (nA, K), device=dev, dtype=torch.int32)
     out = torch.empty(nA, H, device=dev)
-    slot = torch.zeros(1, device=dev)
+    slot = torch.zeros(_lib.RR_AMAX_FLOATS, device=dev)
     check(lib().rr_gather_sum_amax_f32(ptr(src), nB, H, ptr(idx), nA, K, H, None, 0, 0, ptr(out), H, ptr(slot), stream()), "gather")
     ref = torch.where(idx[:, :, None] >= 0, src[idx.clamp(min=0).long()], torch.zeros(1, device=dev)).sum(1)
-    assert torch.allclose(out, ref, atol=1e-5) and float(slot) == float(out.abs().max())
+    assert torch.allclose(out, ref, atol=1e-5) and float(slot.max()) == float(out.abs().max())
     # the fused-epilogue gather: mask, scale, addends, padding-row partials
     y = torch.randn(nA, H, device=dev)
     add = torch.randn(nA, H, device=dev) * 3
@@ -213,8 +215,8 @@ def test_gather_magnitude_outputs():
     e = _lib.GatherEpi()
     e.mask, e.ld_mask, e.mask_scale, e.n_adds, e.ld_add = ptr(y), H, 1.5, 1, H
     e.adds[0] = add.data_ptr()
-    slot2 = torch.zeros(1, device=dev)
+    slot2 = torch.zeros(_lib.RR_AMAX_FLOATS, device=dev)
     e.amax_out = ptr(slot2)
     out2 = torch.empty(nA, H, device=dev)
     check(lib().rr_gather_sum_epi_f32(ptr(src), nB, H, ptr(idx), nA, K, H, ptr(part), 7, H, C.byref(e), ptr(out2), H, stream()), "gather epi")
-    assert float(slot2) == float(out2.abs().max())
+    assert float(slot2.max()) == float(out2.abs().max())
