@@ -21,7 +21,9 @@
  *   - a row index < 0 in any gather table means "skip" (contributes zero); the reference's
  *     padding index 0 is an ordinary row (row 0 = the padding row of BatchMolGraph,
  *     features/featurization.py:255-264) and is gathered like any other.
- *   - reductions are deterministic (fixed order, no float atomics).
+ *   - reductions are deterministic: sums run in a fixed order without float atomics; the only atomics are integer
+ *     maxima of non-negative floats' bit patterns (the magnitude slots of the two-f16-term GEMMs, rr_amax_f32), which are
+ *     exact and order-independent.  Results are run-to-run bit-identical.
  */
 #ifndef REACTRANKER_HIP_H
 #define REACTRANKER_HIP_H

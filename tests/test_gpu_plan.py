@@ -119,16 +119,17 @@ def test_plan_rejects_a_too_small_workspace_before_launching_anything():
     M, S, keep = Fn.StepPlan.build(st, params, out)
     need = int(_lib.lib().rr_reaction_workspace_bytes(C.byref(M), C.byref(S)))
     assert need > 0
+    FL = _lib.RR_PLAN_F16X2_GEMM                     # the layout rr_reaction_workspace_bytes sizes for: the largest (it holds the magnitude slots)
     ws = torch.empty(need, dtype=torch.uint8).cuda()
     S.workspace, S.workspace_bytes = C.c_void_p(ws.data_ptr()), need // 20                   # far below the forward's share
-    assert _lib.lib().rr_reaction_forward(C.byref(M), C.byref(S), 0, _lib.stream()) == -5     # RR_ERR_WORKSPACE
+    assert _lib.lib().rr_reaction_forward(C.byref(M), C.byref(S), FL, _lib.stream()) == -5     # RR_ERR_WORKSPACE
     S.workspace_bytes = need
-    assert _lib.lib().rr_reaction_forward(C.byref(M), C.byref(S), 0, _lib.stream()) == 0
+    assert _lib.lib().rr_reaction_forward(C.byref(M), C.byref(S), FL, _lib.stream()) == 0
     S.workspace_bytes = need - 4096                                                           # forward fits, backward does not
     G = _lib.Grads()
     gr = [torch.empty_like(q) for q in params]
     for gi, wi in enumerate([0, 2, 4, 6, 8, 10, 12, 14]):
         G.w[gi], G.b[gi] = _lib.ptr(gr[wi]), _lib.ptr(gr[wi + 1])
     dout = torch.ones_like(out)
-    assert _lib.lib().rr_reaction_backward(C.byref(M), C.byref(S), _lib.ptr(dout), C.byref(G), 0, _lib.stream()) == -5
+    assert _lib.lib().rr_reaction_backward(C.byref(M), C.byref(S), _lib.ptr(dout), C.byref(G), FL, _lib.stream()) == -5
     torch.cuda.synchronize()
