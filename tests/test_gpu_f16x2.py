@@ -220,3 +220,52 @@ def test_gather_magnitude_outputs():
     out2 = torch.empty(nA, H, device=dev)
     check(lib().rr_gather_sum_epi_f32(ptr(src), nB, H, ptr(idx), nA, K, H, ptr(part), 7, H, C.byref(e), ptr(out2), H, stream()), "gather epi")
     assert float(slot2.max()) == float(out2.abs().max())
+
+
+# every plan shape of tests/test_gpu_plan.py (reactant modes, head layouts, depths 1..16, H = 32 .. 600) through the step plans
+# in BOTH arithmetics: the two-term form must agree with the three-term form (which test_gpu_plan.py holds bit-identical to
+# the per-op mirror and the other modules hold against the oracle) within the parity tolerances, and be run-to-run identical
+from tests.test_gpu_plan import CASES as PLAN_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("H,d,dd,fd,bias,tn,last,tt,F,p,train", PLAN_CASES)
+def test_plans_agree_between_the_two_arithmetics(H, d, dd, fd, bias, tn, last, tt, F, p, train, parity_log):
+    from oracle import ref_cpu as O
+    from reactranker_amd import featurization, synth
+    from tests.test_gpu_model import make_model
+    from tests.test_gpu_plan import _run, _same
+    cfg = dict(hidden_size=H, mpnn_depth=d, mpnn_diff_depth=dd, ffn_depth=fd, use_bias=bias, task_num=tn, ffn_last_layer=last,
+               task_type=tt, add_features_dim=F)
+    w = synth.seeded_weights(O.model_shapes(H, d, dd, fd, tn, F, bias), 5)
+    model = make_model(cfg, w, dropout=p)
+    model = model.train() if train else model.eval()
+    qb = synth.make_queries(17, 4, [7, 3, 9, 5], atoms_lo=5, atoms_hi=14)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    loss = "mle" if tn == 1 else "lin"
+    old = Fn.SplitGemm.f16
+    try:
+        Fn.SplitGemm.f16 = True
+        a = _run(model, rb, pb, qb, 4242, plan=True, loss=loss)
+        _same(a, _run(model, rb, pb, qb, 4242, plan=True, loss=loss))      # atomic maxima are exact: run-to-run bit-identical
+        Fn.SplitGemm.f16 = False
+        b = _run(model, rb, pb, qb, 4242, plan=True, loss=loss)
+    finally:
+        Fn.SplitGemm.f16 = old
+    es = float(((a[0] - b[0]).abs() / (1 + b[0].abs())).max())
+    el = float(((a[1] - b[1]).abs() / (1 + b[1].abs())).max())
+    # gradients: within 5e-5 of the tensor's largest entry - except tensors whose gradient is analytically zero (hazard H5: the
+    # output bias and always-active last-hidden biases under a shift-invariant ranking loss), which are rounding noise in
+    # either arithmetic and only have to BE noise: below 2e-5 of the model's largest gradient entry in both
+    gmax = max(float(v.abs().max()) for v in b[2].values())
+    eg, noise, worst = 0.0, [], ""
+    for k in b[2]:
+        ta, tb = float(a[2][k].abs().max()), float(b[2][k].abs().max())
+        if max(ta, tb) <= 2e-5 * gmax:
+            noise.append(k)
+            continue
+        r = float((a[2][k] - b[2][k]).abs().max()) / tb
+        if r > eg:
+            eg, worst = r, f"{k} (max |g| {tb:.2e} of the model's {gmax:.2e})"
+    parity_log(f"H {H} depth {d}/{dd} train {train}: two-term vs three-term plans - scores {es:.2e}, loss {el:.2e}, worst gradient / its "
+               f"tensor's max {eg:.2e} at {worst}; analytically-zero gradients (noise in both, < 2e-5 of the model's largest): {noise}")
+    assert es <= 1e-5 and el <= 1e-5 and eg <= 5e-5
