@@ -244,7 +244,7 @@ typedef struct rr_linear_args {
   const float* a2_amax;                             /* is >= max |x| over the elements of a1 / a1_sub / a2 this call can read (a
                                                        bound that is too large costs low-end precision, one that is too small
                                                        overflows f16) */
-  float* c_amax_out;                                /* optional outputs (w_packed >= 2): max |C| stored, and the same for dz_out, */
+  float* c_amax_out;                                /* optional outputs (w_packed = 3): max |C| stored, and the same for dz_out, */
   float* dz_amax_out;                               /* maxed into a magnitude slot - the bound the NEXT GEMM needs of this one's
                                                        result without a pass over it (zero the slot first) */
 } rr_linear_args;

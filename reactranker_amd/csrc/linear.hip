@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   const bool persist = CAN_PERSIST && P.persist != 0;
   // the workgroup's running maxima of |C| / |dz_out| (rr_linear_args.c_amax_out / dz_amax_out): two words behind everything else
   unsigned int* const amx = reinterpret_cast<unsigned int*>(smem + PF_OFF + (CAN_PERSIST ? WAVES * 2048 : 0));
-  if (tid == 0) { amx[0] = 0u; amx[1] = 0u; }           // (the prologue's barrier orders this before any use)
+  if (F16 && tid == 0) { amx[0] = 0u; amx[1] = 0u; }    // (the prologue's barrier orders this before any use)
   int64_t g_cur = static_cast<int64_t>(blockIdx.x) * WAVES;            // first 16-row group of the current block
   int64_t g_end = g_cur + WAVES;                                        // end of this workgroup's range
   if (persist) {
@@ -1023,8 +1023,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     split8(v0, v1);
     if (MODE == 2 || MODE == 3) {                      // side output (k1 % 4 == 0: chunks are whole).  Stored HERE, after the
       if (dzrow != nullptr && seg1) {                  // step's load wait: the store then has the whole next MFMA block to retire
-        if (kl < ks) { *reinterpret_cast<f32x4*>(dzrow + kl) = v0; dz_am = rr_amax4(dz_am, v0); }
-        if (kl + 4 < ks) { *reinterpret_cast<f32x4*>(dzrow + kl + 4) = v1; dz_am = rr_amax4(dz_am, v1); }
+        if (kl < ks) { *reinterpret_cast<f32x4*>(dzrow + kl) = v0; if (F16) dz_am = rr_amax4(dz_am, v0); }
+        if (kl + 4 < ks) { *reinterpret_cast<f32x4*>(dzrow + kl + 4) = v1; if (F16) dz_am = rr_amax4(dz_am, v1); }
       }
     }
   };
@@ -1199,7 +1199,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     }
     if (row_ok && n < a.N) {
       *reinterpret_cast<f32x4*>(crow + n) = v;
-      c_am = rr_amax4(c_am, v);
+      if (F16) c_am = rr_amax4(c_am, v);
     }
     return v;
   };
@@ -1307,7 +1307,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
           }
           if (ok) {
             *reinterpret_cast<f32x4*>(a.c + mm * a.ldc + n) = v;
-            c_am = rr_amax4(c_am, v);
+            if (F16) c_am = rr_amax4(c_am, v);
           }
           if (mb_on) {                                               // lanes l, l^1 hold the two halves of 8 consecutive columns
             uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
@@ -1392,8 +1392,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #pragma unroll
     for (int i = 0; i < 5; ++i) d[i] = mb[i];
   }
-  if (a.c_amax_out != nullptr) rr_amax_commit_wave(c_am, amx);
-  if ((MODE == 2 || MODE == 3) && a.dz_amax_out != nullptr && blockIdx.y == 0) {
+  // (the magnitude outputs exist in the two-f16-term instantiations only: the three-term kernels keep their registers)
+  if (F16 && a.c_amax_out != nullptr) rr_amax_commit_wave(c_am, amx);
+  if (F16 && (MODE == 2 || MODE == 3) && a.dz_amax_out != nullptr && blockIdx.y == 0) {
     rr_amax_commit_wave(dz_am, amx + 1);
     dz_am = 0.f;
   }
@@ -1431,7 +1432,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = f32x4(0.f);
   }
-  if (a.c_amax_out != nullptr || a.dz_amax_out != nullptr) {          // (uniform) one atomic per workgroup and output
+  if (F16 && (a.c_amax_out != nullptr || a.dz_amax_out != nullptr)) {  // (uniform) one atomic per workgroup and output
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned int vc = amx[0], vd = amx[1];
@@ -2558,7 +2559,7 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   RR_CHECK_ARG(!a.a_mask_bits || (a.w_packed >= 2 && a.k2 == 0 && !a.a1_sub && !a.a1_idx && a.k1 % 4 == 0));
   RR_CHECK_ARG(!a.mask_bits_out || (a.w_packed >= 2 && a.N % 4 == 0));
   RR_CHECK_ARG(a.act == RR_ACT_NONE || a.act == RR_ACT_RELU);
-  RR_CHECK_ARG((!a.c_amax_out && !a.dz_amax_out) || a.w_packed >= 2);      // (the split kernels' epilogues only)
+  RR_CHECK_ARG((!a.c_amax_out && !a.dz_amax_out) || a.w_packed == 3);      // (the two-f16-term kernels' epilogues only)
   RR_CHECK_ARG(!a.dz_amax_out || a.dz_out);
   RR_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f);
   RR_CHECK_ARG(a.M < (int64_t(1) << 31) * BM);

@@ -364,3 +364,34 @@ def test_round4_entry_points_reject_bad_arguments_without_a_gpu():
     # rr_reaction_saved_f32: needs model / step / output slots
     assert l.rr_reaction_saved_f32(None, None, 0, 0, 0, None, None, None) == -1
     assert l.rr_comm_backend() in (0, 1, 2)
+
+
+def test_revision7_entry_points_reject_bad_arguments_without_a_gpu():
+    """The two-f16-term GEMMs' entry points check their arguments before any launch (ABI revision 7): a w_packed = 3 GEMM
+    without its operand bounds, magnitude outputs asked of a kernel that has none, a null magnitude slot."""
+    l = _lib.lib()
+    one = ctypes.cast(ctypes.c_void_p(256), _lib.c_f32p)
+    assert l.rr_amax_f32(None, 4, 4, 4, one, None) == -1 and l.rr_amax_f32(one, 4, 4, 4, None, None) == -1
+    assert l.rr_amax_f32(one, 4, 8, 4, one, None) == -1                     # ld < cols
+    assert l.rr_amax_f32(one, 0, 4, 4, one, None) == 0                      # no rows: nothing launched
+    A = _lib.LinearArgs()
+    A.M, A.N, A.k1, A.lda1, A.ldc, A.ldw = 64, 32, 32, 32, 32, 0
+    A.a1, A.w, A.c = one, one, one
+    A.mask_scale = 1.0
+    A.w_packed = 3
+    assert l.rr_linear_f32(ctypes.byref(A), None) == -1                     # two f16 terms need a1_amax
+    A.w_packed = 2
+    A.c_amax_out = one
+    assert l.rr_linear_f32(ctypes.byref(A), None) == -1                     # magnitude outputs: w_packed = 3 only
+    A.c_amax_out = None
+    A.dz_amax_out, A.w_packed = one, 3
+    A.a1_amax = one
+    assert l.rr_linear_f32(ctypes.byref(A), None) == -1                     # dz_amax_out without dz_out
+    W = _lib.WgradArgs()
+    W.M, W.N, W.k1, W.ld_dy, W.ldx1, W.ld_dw = 64, 32, 32, 32, 32, 32
+    W.dy, W.x1, W.dw, W.workspace, W.workspace_bytes = one, one, one, 256, 1 << 30
+    W.mask_scale, W.split = 1.0, 2
+    assert l.rr_linear_wgrad_f32(ctypes.byref(W), None) == -1               # split = 2 needs dy_amax / x1_amax
+    W.split = 3
+    assert l.rr_linear_wgrad_f32(ctypes.byref(W), None) == -1
+    assert _lib.RR_AMAX_FLOATS == 512 and _lib.RR_PLAN_F16X2_GEMM == 32
