@@ -38,7 +38,9 @@ def main():
                 os.environ.pop(k, None)
             for k in ks:
                 os.environ[k] = "1"
-            Fn.SplitGemm.f16 = "RR_F16X2" in ks            # (Python-side switches: plan flags)
+            # (Python-side switches: plan flags.)  The two-f16-term GEMMs are the default; "BF16X3" as a knob selects the
+            # three-term form for that variant - or, when some variant names RR_F16X2, only those variants run two terms
+            Fn.SplitGemm.f16 = ("RR_F16X2" in ks) if "RR_F16X2" in knobs else ("BF16X3" not in ks)
             Fn.SideStream.enabled = "NOSIDE" not in ks
             Fn.AuxStream.enabled = "NOAUX" not in ks
             for i in range(4):
