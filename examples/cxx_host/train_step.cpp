@@ -160,7 +160,11 @@ int main(int argc, char** argv) {
   if (s.workspace_bytes == 0) { fprintf(stderr, "rr_reaction_workspace_bytes rejected the step\n"); return 4; }
   s.workspace = dmalloc<uint8_t>(s.workspace_bytes);
 
-  RR_OK_(rr_reaction_forward(&m, &s, 0, st));
+  // plan flags: the two-f16-term GEMMs (half the matrix instructions of the three-bf16-term form; the plans find every operand's
+  // magnitude themselves) unless RR_CXX_PLAN_FLAGS says otherwise; forward and backward of a step get the same flags
+  const char* fl_env = getenv("RR_CXX_PLAN_FLAGS");
+  const int plan_flags = fl_env != nullptr ? atoi(fl_env) : RR_PLAN_F16X2_GEMM;
+  RR_OK_(rr_reaction_forward(&m, &s, plan_flags, st));
   // ListMLE over the step's queries (scores = first output column)
   std::vector<int32_t> seg(Q + 1, 0);
   const int32_t* scope = reinterpret_cast<const int32_t*>(blob + toc["scope"].off);
@@ -184,7 +188,7 @@ int main(int argc, char** argv) {
     G.w[i] = dmalloc<float>(nw); G.b[i] = dmalloc<float>(Ls[i]->out);
     gbuf.push_back({G.w[i], nw}); gbuf.push_back({G.b[i], static_cast<size_t>(Ls[i]->out)});
   }
-  RR_OK_(rr_reaction_backward(&m, &s, dout, &G, 0, st));
+  RR_OK_(rr_reaction_backward(&m, &s, dout, &G, plan_flags, st));
   // The data-parallel exchange of a multi-GPU job (one process per GPU, whole queries per rank): ONE sum all-reduce per
   // gradient buffer over an RCCL communicator, scaled to the mean over equal shards.  This example is one process, so its
   // communicator has one rank and the exchange is the identity - the call sequence is what a rank of an N-GPU job runs

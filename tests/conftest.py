@@ -23,10 +23,10 @@ def golden_dir():
 # The whole-step plans run their encoder GEMMs on two f16 terms per operand by default (functions.SplitGemm.f16: 22
 # significant bits, three matrix instructions per k-step) or on three exact bf16 terms (six).  The modules that compare the
 # HIP path with the oracle / the reference's vectors run in BOTH modes; the modules that compare two HIP paths bit for bit
-# (the per-op Python mirror and the C++ host example only know the three-term form) are pinned to it.
+# (the per-op Python mirror's bounds come from separate passes) are pinned to the three-term form.
 BOTH_GEMM_MODES = {"test_gpu_model", "test_gpu_headline_kernels", "test_gpu_trainers", "test_gpu_api_parity"}
 DEFAULT_MODE_ONLY = {"test_train_mode_plan_path_above_8192_rows_against_fp64_oracle_h600_d6"}
-BF16X3_ONLY = {"test_gpu_plan", "test_gpu_cxx_host", "test_gpu_dp_trainers", "test_gpu_split"}
+BF16X3_ONLY = {"test_gpu_plan", "test_gpu_dp_trainers", "test_gpu_split"}      # (test_gpu_cxx_host sets the arithmetic itself)
 
 
 def pytest_generate_tests(metafunc):

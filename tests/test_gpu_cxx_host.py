@@ -26,9 +26,22 @@ def _build():
         pytest.skip("cannot build the C++ host example here: " + r.stderr[-300:])
 
 
+@pytest.mark.parametrize("arith", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("p,depth,ddepth", [(0.15, 3, 3), (0.0, 3, 3), (0.2, 1, 2)])
-def test_cxx_host_step_matches_the_python_modules(tmp_path, p, depth, ddepth):
+def test_cxx_host_step_matches_the_python_modules(tmp_path, p, depth, ddepth, arith):
+    """both hosts issue the same step plans: in either GEMM arithmetic (the C++ host's default is the two-f16-term one,
+    RR_CXX_PLAN_FLAGS=0 selects three bf16 terms) the results must agree to the last bit of what the JSON carries"""
     _build()
+    from reactranker_amd import functions as Fn
+    old_f16 = Fn.SplitGemm.f16
+    Fn.SplitGemm.f16 = arith == "f16x2"
+    try:
+        _cxx_case(tmp_path, p, depth, ddepth, arith)
+    finally:
+        Fn.SplitGemm.f16 = old_f16
+
+
+def _cxx_case(tmp_path, p, depth, ddepth, arith):
     H, F = 64, 1
     cfg = dict(hidden_size=H, mpnn_depth=depth, mpnn_diff_depth=ddepth, ffn_depth=3, use_bias=True, task_num=1,
                ffn_last_layer="with_softplus", task_type=None, add_features_dim=F)
@@ -53,7 +66,8 @@ def test_cxx_host_step_matches_the_python_modules(tmp_path, p, depth, ddepth):
     l = RL.MLEloss()(out, qb.scope, torch.tensor(qb.targets), 0)
     l.sum().backward()
     want_sums = [float(q.grad.double().sum()) for q in model.flat_params() if q is not None]
-    r = subprocess.run([EXE, shard, "0", wfile, repr(p), str(seed)], capture_output=True, text=True, timeout=120)
+    env = dict(os.environ, RR_CXX_PLAN_FLAGS="32" if arith == "f16x2" else "0")       # RR_PLAN_F16X2_GEMM
+    r = subprocess.run([EXE, shard, "0", wfile, repr(p), str(seed)], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["M"] == pb.n_mols
