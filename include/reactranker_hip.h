@@ -150,6 +150,10 @@ int rr_gather_diff_f32(const float* a, int64_t n_a, int64_t ld_a, const int32_t*
  * message after the first W_h of a de-duplicated reactant (same mask stream as rr_linear_f32's epilogue). */
 int rr_gather_dropout_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int H,
                           float drop_p, uint64_t drop_seed, float* out, int64_t ld_out, rr_stream_t stream);
+/* The same with a magnitude output (see rr_gather_epi.amax_out): max |out| maxed into the slot amax_out (may be NULL). */
+int rr_gather_dropout_amax_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int H,
+                               float drop_p, uint64_t drop_seed, float* out, int64_t ld_out, float* amax_out,
+                               rr_stream_t stream);
 
 /* out[0:H] (+)= sum_r w[r] * x[r, 0:H]   (w == NULL -> all ones).
  * Backward of the padding row: the reference gathers row 0 (K - deg(a)) times per atom
@@ -397,6 +401,11 @@ int rr_segment_mean_bwd_masked_f32(const float* dout, int64_t ld_dout, const int
                                    float drop_p, uint64_t drop_seed,
                                    const float* mask, int64_t ld_mask, const uint8_t* mask_bits, float mask_scale,
                                    float* dx, int64_t ldx, rr_stream_t stream);
+/* The same with a magnitude output (see rr_gather_epi.amax_out): max |dx| maxed into the slot amax_out (may be NULL). */
+int rr_segment_mean_bwd_masked_amax_f32(const float* dout, int64_t ld_dout, const int32_t* a_scope,
+                                        const int32_t* atom2mol, int64_t n_atoms, int H, int F, float drop_p,
+                                        uint64_t drop_seed, const float* mask, int64_t ld_mask, const uint8_t* mask_bits,
+                                        float mask_scale, float* dx, int64_t ldx, float* amax_out, rr_stream_t stream);
 
 /* ------------------------------------------------------------------ ranking losses - */
 /* Lists are described by seg_off[Q+1] (prefix sums of the reference's `scope` list);

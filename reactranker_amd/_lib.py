@@ -134,12 +134,15 @@ _SIGS = {
                                     c_stream]),
     "rr_segment_mean_bwd_masked_f32": (i32, [c_f32p, i64, c_i32p, c_i32p, i64, i32, i32, f32, u64, c_f32p, i64, C.c_void_p, f32,
                                              c_f32p, i64, c_stream]),
+    "rr_segment_mean_bwd_masked_amax_f32": (i32, [c_f32p, i64, c_i32p, c_i32p, i64, i32, i32, f32, u64, c_f32p, i64, C.c_void_p, f32,
+                                             c_f32p, i64, c_f32p, c_stream]),
     "rr_gather_sum_masked_f32": (i32, [c_f32p, c_f32p, i64, i64, c_i32p, i64, i32, i32, f32, c_f32p, i64, c_stream]),
     "rr_gather_sum_dropmask_f32": (i32, [c_f32p, i64, i64, c_f32p, i64, c_i32p, i64, i32, i32, f32, u64, f32, c_f32p, i64, c_stream]),
     "rr_gather_sum_csr_f32": (i32, [c_f32p, i64, i64, c_i32p, c_i32p, i64, i32, c_f32p, i64, c_stream]),
     "rr_build_fbonds_f32": (i32, [c_f32p, i64, i64, i32, c_i32p, c_f32p, i64, i32, i64, c_f32p, i64, c_stream]),
     "rr_gather_diff_f32": (i32, [c_f32p, i64, i64, c_i32p, c_f32p, i64, i64, c_i32p, i64, i32, c_f32p, i64, c_stream]),
     "rr_gather_dropout_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, f32, u64, c_f32p, i64, c_stream]),
+    "rr_gather_dropout_amax_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, f32, u64, c_f32p, i64, c_f32p, c_stream]),
     "rr_colsum_workspace_bytes": (C.c_size_t, [i64, i32]),
     "rr_weighted_colsum_f32": (i32, [c_f32p, i64, i64, c_f32p, i32, c_f32p, i32, C.c_void_p, C.c_size_t, c_stream]),
     "rr_linear_f32": (i32, [C.POINTER(LinearArgs), c_stream]),

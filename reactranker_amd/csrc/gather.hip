@@ -518,9 +518,10 @@ template <int VEC>
 __global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __restrict__ src, int64_t ld_src,
                                                              const int32_t* __restrict__ idx, int64_t n_out, int HV, int H,
                                                              uint32_t thr, float keep_scale, uint64_t seed,
-                                                             float* __restrict__ out, int64_t ld_out) {
+                                                             float* __restrict__ out, int64_t ld_out, float* __restrict__ amax_out) {
   using V = typename Vec<VEC>::T;
   const int64_t total = n_out * HV;
+  float am = 0.f;
 #ifdef RR_GATHER_WALK
   if constexpr (VEC == 4) {
     int64_t wbeg, wend;
@@ -534,8 +535,10 @@ __global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __rest
         for (int q = 0; q < 4; ++q) v[q] = rr_hash_lane(w, q) >= thr ? v[q] * keep_scale : 0.f;
       }
       st<4>(out + r * ld_out + c, v);
+      am = amax_fold(am, v);
     };
     gather_walk<1, false>(src, ld_src, idx, 1, HV, wbeg, wend, pre, fin);
+    amax_commit(am, amax_out);
     return;
   }
 #endif
@@ -555,7 +558,9 @@ __global__ void __launch_bounds__(256) gather_dropout_kernel(const float* __rest
       }
     }
     st<VEC>(out + r * ld_out + c, v);
+    am = amax_fold(am, v);
   }
+  amax_commit(am, amax_out);
 }
 
 // f_bonds[b] = [ f_atoms[b2a[b], 0:Fa] | fbond[b, 0:Fb] | 0 ... ]  (features/featurization.py:198-199: a directed bond's
@@ -711,9 +716,10 @@ __global__ void __launch_bounds__(256) segment_mean_bwd_vec_kernel(const float* 
                                                                    uint64_t seed, float* __restrict__ dx, int64_t ldx,
                                                                    const float* __restrict__ mask, int64_t ld_mask,
                                                                    const uint8_t* __restrict__ mask_bits, int64_t bits_row,
-                                                                   float mask_scale) {
+                                                                   float mask_scale, float* __restrict__ amax_out) {
   const int64_t total = n_atoms * HV;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  float am = 0.f;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
     const int64_t a = e / HV;
     const int c = static_cast<int>(e - a * HV) * 4;
@@ -748,7 +754,9 @@ __global__ void __launch_bounds__(256) segment_mean_bwd_vec_kernel(const float* 
       v.z = m.z > 0.f ? v.z * mask_scale : 0.f; v.w = m.w > 0.f ? v.w * mask_scale : 0.f;
     }
     *reinterpret_cast<float4*>(dx + a * ldx + c) = v;
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  amax_commit(am, amax_out);
 }
 
 }  // namespace
@@ -907,6 +915,12 @@ int rr_gather_diff_f32(const float* a, int64_t n_a, int64_t ld_a, const int32_t*
 
 int rr_gather_dropout_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int H,
                           float drop_p, uint64_t drop_seed, float* out, int64_t ld_out, rr_stream_t stream) {
+  return rr_gather_dropout_amax_f32(src, n_src, ld_src, idx, n_out, H, drop_p, drop_seed, out, ld_out, nullptr, stream);
+}
+
+int rr_gather_dropout_amax_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int H,
+                               float drop_p, uint64_t drop_seed, float* out, int64_t ld_out, float* amax_out,
+                               rr_stream_t stream) {
   RR_CHECK_ARG(src && idx && out && n_src >= 0 && n_out >= 0 && H >= 1 && ld_src >= H && ld_out >= H);
   RR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
   if (n_out == 0) return RR_OK;
@@ -916,10 +930,10 @@ int rr_gather_dropout_f32(const float* src, int64_t n_src, int64_t ld_src, const
   const bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(src) && rr_aligned16(out);
   if (vec) {
     gather_dropout_kernel<4><<<rr_grid_for(n_out * (H / 4), 256), 256, 0, s>>>(src, ld_src, idx, n_out, H / 4, H, thr, ks,
-                                                                             drop_seed, out, ld_out);
+                                                                             drop_seed, out, ld_out, amax_out);
   } else {
     gather_dropout_kernel<1><<<rr_grid_for(n_out * H, 256), 256, 0, s>>>(src, ld_src, idx, n_out, H, H, thr, ks,
-                                                                         drop_seed, out, ld_out);
+                                                                         drop_seed, out, ld_out, amax_out);
   }
   return rr_launch_status();
 }
@@ -985,6 +999,14 @@ int rr_segment_mean_bwd_masked_f32(const float* dout, int64_t ld_dout, const int
                                    int64_t n_atoms, int H, int F, float drop_p, uint64_t drop_seed, const float* mask,
                                    int64_t ld_mask, const uint8_t* mask_bits, float mask_scale, float* dx, int64_t ldx,
                                    rr_stream_t stream) {
+  return rr_segment_mean_bwd_masked_amax_f32(dout, ld_dout, a_scope, atom2mol, n_atoms, H, F, drop_p, drop_seed, mask, ld_mask,
+                                             mask_bits, mask_scale, dx, ldx, nullptr, stream);
+}
+
+int rr_segment_mean_bwd_masked_amax_f32(const float* dout, int64_t ld_dout, const int32_t* a_scope, const int32_t* atom2mol,
+                                        int64_t n_atoms, int H, int F, float drop_p, uint64_t drop_seed, const float* mask,
+                                        int64_t ld_mask, const uint8_t* mask_bits, float mask_scale, float* dx, int64_t ldx,
+                                        float* amax_out, rr_stream_t stream) {
   RR_CHECK_ARG(dout && a_scope && atom2mol && dx && n_atoms >= 0 && H >= 1 && F >= 0 && ld_dout >= H && ldx >= H);
   RR_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
   RR_CHECK_ARG((mask || mask_bits) && (!mask || ld_mask >= H));
@@ -996,7 +1018,7 @@ int rr_segment_mean_bwd_masked_f32(const float* dout, int64_t ld_dout, const int
   // 1.6x of the write-only HBM rate, so its per-atom arithmetic is not what the step waits for.)
   segment_mean_bwd_vec_kernel<<<rr_grid_for(n_atoms * (H / 4), 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
       dout, ld_dout, a_scope, atom2mol, n_atoms, H / 4, H + F, rr_drop_threshold(drop_p), 1.0f / (1.0f - drop_p), drop_seed,
-      dx, ldx, mask_bits ? nullptr : mask, ld_mask, mask_bits, rr_mask_bits_row_bytes(H), mask_scale);
+      dx, ldx, mask_bits ? nullptr : mask, ld_mask, mask_bits, rr_mask_bits_row_bytes(H), mask_scale, amax_out);
   return rr_launch_status();
 }
 
@@ -1011,7 +1033,7 @@ int rr_segment_mean_bwd_f32(const float* dout, int64_t ld_dout, const int32_t* a
   if (H % 4 == 0 && ldx % 4 == 0 && rr_aligned16(dx)) {
     segment_mean_bwd_vec_kernel<<<rr_grid_for(n_atoms * (H / 4), 256), 256, 0, s>>>(
         dout, ld_dout, a_scope, atom2mol, n_atoms, H / 4, H + F, thr, 1.0f / (1.0f - drop_p), drop_seed, dx, ldx,
-        nullptr, 0, nullptr, 0, 1.0f);
+        nullptr, 0, nullptr, 0, 1.0f, nullptr);
   } else {
     segment_mean_bwd_kernel<<<rr_grid_for(n_atoms * H, 256), 256, 0, s>>>(dout, ld_dout, a_scope, atom2mol, n_atoms, H,
                                                                           F, thr, 1.0f / (1.0f - drop_p), drop_seed, dx,

@@ -81,10 +81,14 @@ int stream_wait(hipStream_t waiter, hipStream_t signaller) {
 struct Packed { const float* w; int64_t ld; int mode; };   // mode = rr_linear_args.w_packed (1 f32 layout, 2 bf16 terms)
 
 // Two-f16-term GEMMs (RR_PLAN_F16X2_GEMM) need an upper bound of every operand tensor's magnitude.  The plan keeps one
-// magnitude slot (RR_AMAX_FLOATS floats, include/reactranker_hip.h) per tensor in a block of the workspace (zeroed at the start of the forward / of the backward's own part), found
-// by one rr_amax_f32 pass on the stream of the tensor's FIRST consumer and shared by every later one (a forward
-// activation's slot serves its weight gradient in the backward: the workspace is kept).  Tensors are known by address:
-// every arena allocation and the step's input arrays are recorded with their shape.
+// magnitude slot (RR_AMAX_FLOATS floats, include/reactranker_hip.h) per tensor in a block of the workspace, zeroed at the
+// start of the forward / of the backward's own part.  A tensor's slot is filled by the kernel that PRODUCES it where that
+// kernel can (amax_claim: the split GEMM's epilogue, the gather kernels, the readout's adjoint - the producer maxes what it
+// stores into the slot),
+// otherwise by one rr_amax_f32 pass on the stream of the tensor's first consumer (amax_of: the step's input features and the
+// outputs of the few kernels without a magnitude output), and serves every later consumer - a forward activation's slot
+// serves its weight gradient in the backward: the workspace is kept.  Tensors are known by address: every arena allocation
+// and the step's input arrays are recorded with their shape.
 constexpr int MAX_TENSORS = 768, MAX_AMAX = 256;
 struct TensorRec { const float* p; int64_t rows, cols, ld; float* amax; };
 
@@ -93,7 +97,7 @@ struct Ctx {
   int status;
   Arena ar;
   bool f16;                           // split GEMMs on two f16 terms (needs split)
-  float* amax_base;                   // MAX_AMAX floats (null in a measuring pass)
+  float* amax_base;                   // MAX_AMAX magnitude slots (null in a measuring pass)
   int namax, ntr;
   TensorRec tr[MAX_TENSORS];
   float* alloc(int64_t rows, int64_t cols) {            // arena tensor, remembered for amax_of()
@@ -331,7 +335,7 @@ void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk
     set_w(a, pk.enc_wi); a.bias = m.enc_wi.b; a.act = RR_ACT_RELU;
     a.c = S.msgs[0]; a.ldc = H; a.c_pre = inp; a.ld_pre = H;
     S.bits[0] = mask_bits(c, pk.enc_wi, g.nB, H); a.mask_bits_out = S.bits[0];           // relu'(input) for the backward
-    lin(c, a, st);                                                   // :80-81
+    lin(c, a, st);                                                              // :80-81
   }
   for (int it = 0; it < depth - 1; ++it) {                                              // :84
     S.amsgs[it] = c.alloc(g.nA, H);
@@ -344,7 +348,7 @@ void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk
     a.drop_p = p; a.drop_seed = site_seed(seed, it);
     a.c = S.msgs[it + 1]; a.ldc = H;
     S.bits[it + 1] = mask_bits(c, pk.enc_wh, g.nB, H); a.mask_bits_out = S.bits[it + 1];
-    lin(c, a, st);                                                   // :91-97
+    lin(c, a, st);                                                              // :91-97
   }
   S.a_last = c.alloc(g.nA, H);
   gather_sum(c, S.msgs[depth - 1], g.nB, H, g.a2b, g.nA, g.K, H, S.a_last, H, st);     // :101-102
@@ -354,7 +358,7 @@ void mpn_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& pk
   set_w(a, pk.enc_wo); a.bias = m.enc_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 1000);
   a.c = S.h; a.ldc = H;
   S.bits_h = mask_bits(c, pk.enc_wo, g.nA, H); a.mask_bits_out = S.bits_h;
-  lin(c, a, st);                                                     // :103-105
+  lin(c, a, st);                                                              // :103-105
 }
 
 // the same for a batch whose molecules repeat: the deterministic prefix runs once per distinct molecule
@@ -379,11 +383,11 @@ void mpn_forward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_
     a.a1_sub = S.msg0_u; a.lda1_sub = H; a.a1_sub_idx = gu.b2revb;
     set_w(a, pk.enc_wh); a.bias = m.enc_wh.b; a.residual = inp_u; a.ldr = H; a.act = RR_ACT_RELU;
     a.c = z1_u; a.ldc = H;
-    lin(c, a, st);                                                   // pre-dropout, shared
+    lin(c, a, st);                                                              // pre-dropout, shared
   }
   S.msgs[0] = nullptr;
   S.msgs[1] = c.alloc(g.nB, H);
-  RR_TRY(c, rr_gather_dropout_f32(z1_u, gu.nB, H, bmap, g.nB, H, p, site_seed(seed, 0), S.msgs[1], H, st));   // per-copy masks
+  RR_TRY(c, rr_gather_dropout_amax_f32(z1_u, gu.nB, H, bmap, g.nB, H, p, site_seed(seed, 0), S.msgs[1], H, amax_claim(c, S.msgs[1]), st));   // per-copy masks
   S.z1_u = z1_u;
   S.seed0 = site_seed(seed, 0);
   for (int it = 1; it < depth - 1; ++it) {
@@ -424,7 +428,7 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
     a.drop_p = depth == 0 ? p : 0.f; a.drop_seed = site_seed(seed, 2000);              // :221 (depth 0: dropout(message))
     a.c = S.msgs[0]; a.ldc = H; a.c_pre = inp; a.ld_pre = H;
     S.bits[0] = mask_bits(c, pk.dif_wi, g.nA, H); a.mask_bits_out = S.bits[0];
-    lin(c, a, st);                                                   // :194-195
+    lin(c, a, st);                                                              // :194-195
   }
   if (depth > 0) {
     for (int it = 0; it < depth - 1; ++it) {                                            // :199
@@ -437,7 +441,7 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
       a.drop_p = p; a.drop_seed = site_seed(seed, 2001 + it);
       a.c = S.msgs[it + 1]; a.ldc = H;
       S.bits[it + 1] = mask_bits(c, pk.dif_wh, g.nA, H); a.mask_bits_out = S.bits[it + 1];
-      lin(c, a, st);                                                 // :202-213
+      lin(c, a, st);                                                              // :202-213
     }
     S.a_last = c.alloc(g.nA, H);
     gather_sum(c, S.msgs[depth - 1], g.nA, H, g.a2a, g.nA, g.K, H, S.a_last, H, st);   // :215-216
@@ -448,7 +452,7 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
     set_w(a, pk.dif_wo); a.bias = m.dif_wo.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 3000);
     a.c = S.hid; a.ldc = H;
     S.bits_hid = mask_bits(c, pk.dif_wo, g.nA, H); a.mask_bits_out = S.bits_hid;
-    lin(c, a, st);                                                   // :217-219
+    lin(c, a, st);                                                              // :217-219
   } else {
     S.a_last = nullptr;
     S.hid = S.msgs[0];
@@ -717,8 +721,8 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
     // hid = drop(relu(.)): the readout's adjoint applies that pattern as it writes (dZ of W_o), so both column blocks
     // of W_o read a plain operand; the message-passing iterations below follow mpn_backward
     float* dz_o = d_hid;
-    RR_TRY(c, rr_segment_mean_bwd_masked_f32(dvecs, ld_dvecs, g.a_scope, g.atom2mol, g.nA, H, F, p, out_seed, S.hid, H, S.bits_hid,
-                                             ks, dz_o, H, st));
+    RR_TRY(c, rr_segment_mean_bwd_masked_amax_f32(dvecs, ld_dvecs, g.a_scope, g.atom2mol, g.nA, H, F, p, out_seed, S.hid, H, S.bits_hid,
+                                                  ks, dz_o, H, amax_claim(c, dz_o), st));
     const Packed wo_x = T.dif_wo_x, wo_a = T.dif_wo_a;
     d_x = c.alloc(g.nA, H);
     {

@@ -269,3 +269,37 @@ def test_plans_agree_between_the_two_arithmetics(H, d, dd, fd, bias, tn, last, t
     parity_log(f"H {H} depth {d}/{dd} train {train}: two-term vs three-term plans - scores {es:.2e}, loss {el:.2e}, worst gradient / its "
                f"tensor's max {eg:.2e} at {worst}; analytically-zero gradients (noise in both, < 2e-5 of the model's largest): {noise}")
     assert es <= 1e-5 and el <= 1e-5 and eg <= 5e-5
+
+
+def test_magnitude_outputs_of_the_dropout_gather_and_the_readout_adjoint():
+    """rr_gather_dropout_amax_f32 / rr_segment_mean_bwd_masked_amax_f32: same results as the entry points without the slot,
+    and the slot holds the stored tensor's largest magnitude"""
+    torch.manual_seed(9)
+    H, nU, nB, p = 300, 3000, 40000, 0.1
+    z = torch.relu(torch.randn(nU, H, device=dev)) * 7
+    bmap = torch.randint(0, nU, (nB,), device=dev, dtype=torch.int32)
+    o1 = torch.empty(nB, H, device=dev)
+    o2 = torch.empty(nB, H, device=dev)
+    slot = torch.zeros(_lib.RR_AMAX_FLOATS, device=dev)
+    check(lib().rr_gather_dropout_f32(ptr(z), nU, H, ptr(bmap), nB, H, p, 99, ptr(o1), H, stream()), "gather_dropout")
+    check(lib().rr_gather_dropout_amax_f32(ptr(z), nU, H, ptr(bmap), nB, H, p, 99, ptr(o2), H, ptr(slot), stream()), "gather_dropout_amax")
+    assert torch.equal(o1, o2) and float(slot.max()) == float(o2.abs().max())
+    # readout adjoint with the mask of the layer below
+    M, F = 500, 1
+    sizes = torch.randint(5, 25, (M,))
+    starts = torch.cumsum(sizes, 0) - sizes + 1                      # atom 0 is the padding row
+    nA = int(sizes.sum()) + 1
+    a_scope = torch.stack([starts, sizes], 1).to(torch.int32).to(dev).contiguous()
+    atom2mol = torch.full((nA,), -1, dtype=torch.int32)
+    for mi in range(M):
+        atom2mol[int(starts[mi]):int(starts[mi] + sizes[mi])] = mi
+    atom2mol = atom2mol.to(dev)
+    dvecs = torch.randn(M, 304, device=dev) * 1e-4
+    hid = torch.randn(nA, H, device=dev)
+    d1 = torch.empty(nA, H, device=dev)
+    d2 = torch.empty(nA, H, device=dev)
+    slot2 = torch.zeros(_lib.RR_AMAX_FLOATS, device=dev)
+    args = (ptr(dvecs), 304, ptr(a_scope), ptr(atom2mol), nA, H, F, p, 1234, ptr(hid), H, None, 1.0 / (1 - p))
+    check(lib().rr_segment_mean_bwd_masked_f32(*args, ptr(d1), H, stream()), "segment_mean_bwd_masked")
+    check(lib().rr_segment_mean_bwd_masked_amax_f32(*args, ptr(d2), H, ptr(slot2), stream()), "segment_mean_bwd_masked_amax")
+    assert torch.equal(d1, d2) and float(d2.abs().max()) > 0 and float(slot2.max()) == float(d2.abs().max())
