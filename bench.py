@@ -674,14 +674,25 @@ def main():
             # handed to the prefetcher), the reader thread makes its first HIP calls - 37 / 87 / ~95 ms on three boxes, which
             # was ALL of the 0.925-0.975x the 200-step leg showed (its per-step median was already below the resident
             # region's).  A real epoch is 1563 steps: its first step is noise there, it was 8 % of a 200-step leg.
-            n_warm = min(2, n)
-            pf = SH.StepPrefetcher(rd, device, list(range(n_warm)) + list(range(n)), depth=3)
+            # ... and they are the epoch's LARGEST steps (ShardSet.largest): the caching allocator then holds a block for every
+            # later, smaller request - without this 4 device allocations (126 MB) fell inside the 200 timed steps, each a
+            # hipMalloc that usually costs a millisecond and once in a while 50 (one run of six: a 58 ms step, 0.937x)
+            warm = rd.largest(min(2, n))
+            n_warm = len(warm)
+            pf = SH.StepPrefetcher(rd, device, warm + list(range(n)), depth=3)
             startup = pf.prime()                          # start-up latency of the pipeline, reported, not timed
             it = iter(pf)
             for _ in range(n_warm):                       # the SAME pipeline: its buffers, its thread, its copy stream are
                 R.train_step(next(it))                    # in steady state when the timed epoch starts
             R.fence()
+            ms0 = torch.cuda.memory_stats(device)
+            ws0 = Fn._WorkspacePool.allocs
             e_secs, e_per, _ = R.timed(lambda i: next(it), n)
+            ms1 = torch.cuda.memory_stats(device)
+            # device allocations INSIDE the timed epoch (a fresh hipMalloc is 40-180 ms on this pool: the slowest step, if any)
+            mem = dict(device_allocs=int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+                       reserved_mb_grown=round((ms1.get("reserved_bytes.all.current", 0) - ms0.get("reserved_bytes.all.current", 0)) / 1e6, 1),
+                       workspace_allocs=int(Fn._WorkspacePool.allocs - ws0))
             pf.close()
             te = torch.tensor([e_secs], dtype=torch.float64, device=device)
             if world > 1:
@@ -696,7 +707,7 @@ def main():
                          shard_gb_per_rank=round(sum(os.path.getsize(p) for p in shard_paths) / 1e9, 3),
                          step_mb=round(rd.max_step_bytes / 1e6, 2), h2d_gb_per_rank=round(pf.bytes_copied / 1e9, 3),
                          consumer_wait_s=round(pf.wait_s, 4), prefetch_startup_s=round(startup, 4), pack_s=round(t_shards, 2),
-                         page_cache="hot", warmup_steps=min(2, n),
+                         page_cache="hot", warmup_steps=min(2, n), allocator=mem,
                          note="every step read once from shard files written seconds earlier by this run, i.e. served from the "
                               "page cache, not from the disk (page cache -> pinned staging -> one H2D copy per step on a "
                               "copy stream, 3 slots); only the 22 bond columns of f_bonds and the distinct reactants' "
@@ -704,7 +715,7 @@ def main():
                               "from the timed region")
             log(f"epoch stream: {e_secs / n * 1e3:.2f} ms/step, {qps_e:.0f} queries/s")
             log("epoch stream detail: " + json.dumps({k: epoch[k] for k in ("vs_resident", "step_ms", "slowest_steps", "consumer_wait_s",
-                                                                           "prefetch_startup_s", "h2d_gb_per_rank")}))
+                                                                           "prefetch_startup_s", "h2d_gb_per_rank", "allocator")}))
         except Exception as e:                            # noqa: BLE001
             epoch = dict(skipped=f"{type(e).__name__}: {e}")
             log(f"epoch stream failed: {epoch['skipped']}")

@@ -933,6 +933,7 @@ class _WorkspacePool:
     the allocator's own: a buffer comes back after its backward was enqueued, and that backward joins the library's
     side streams to the caller's stream before it returns."""
     free: List[torch.Tensor] = []
+    allocs = 0               # buffers allocated so far (bench.py: none should fall inside a timed region)
 
     @classmethod
     def take(cls, nbytes: int, device) -> torch.Tensor:
@@ -943,6 +944,7 @@ class _WorkspacePool:
         if best is not None:
             return cls.free.pop(best)
         cls.free = [t for t in cls.free if t.device != device]          # too small for this model now: let them go
+        cls.allocs += 1
         return torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
 
     @classmethod

@@ -206,6 +206,13 @@ class ShardSet:
     def __len__(self) -> int:
         return len(self._where)
 
+    def largest(self, k: int = 2) -> List[int]:
+        """the k steps with the most atoms + bonds: run these first (untimed / as the first steps of an epoch) and every
+        buffer the allocator has to find for a later step already exists - a fresh hipMalloc in the middle of an epoch is
+        a 40-180 ms step"""
+        size = self.index[:, 4] + self.index[:, 5]
+        return [int(i) for i in np.argsort(size, kind="stable")[::-1][:max(0, k)]]
+
     def meta(self, i: int) -> dict:
         ri, j = self._where[i]
         return self.readers[ri].meta(j)
