@@ -99,3 +99,23 @@ def test_load_packed_keeps_molecule_identities_for_dedup(tmp_path):
         assert np.array_equal(ub0._host[k], ub1._host[k]), k
     for x, y in zip(b.unique_bonds(), l.unique_bonds()):
         assert np.array_equal(x, y)
+
+
+def test_largest_steps_come_first_for_the_allocator_warm_up(tmp_path):
+    """ShardSet.largest(k): the steps with the most atoms + bonds (what a streamed epoch should run first, bench.py)"""
+    from reactranker_amd import featurization, shards, synth
+    paths = []
+    sizes = []
+    for f, cands in enumerate(([3, 9], [5, 2, 7])):
+        p = str(tmp_path / f"s{f}.rrshard")
+        with shards.ShardWriter(p) as w:
+            for i, c in enumerate(cands):
+                qb = synth.make_queries(10 * f + i, 2, [c, c + 1], atoms_lo=5, atoms_hi=9)
+                rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+                w.add_step(rb, pb, qb.scope, qb.targets, qb.add_features)
+        paths.append(p)
+    rd = shards.ShardSet(paths)
+    size = [rd.meta(i)["nA"] + rd.meta(i)["nB"] for i in range(len(rd))]
+    top = rd.largest(2)
+    assert len(top) == 2 and size[top[0]] == max(size) and size[top[1]] == sorted(size)[-2]
+    assert rd.largest(0) == [] and len(rd.largest(99)) == len(rd)
