@@ -43,6 +43,7 @@ def main():
             Fn.SplitGemm.f16 = ("RR_F16X2" in ks) if "RR_F16X2" in knobs else ("BF16X3" not in ks)
             Fn.SideStream.enabled = "NOSIDE" not in ks
             Fn.AuxStream.enabled = "NOAUX" not in ks
+            Fn.AuxStream.backward = "AUXBWD" in ks         # reactant-encoder backward on the aux stream (RR_PLAN_AUX_BACKWARD)
             for i in range(4):
                 R.train_step(R.pool[i % len(R.pool)])
             secs, per, _ = R.timed(lambda i: R.pool[i % len(R.pool)], a.steps)
