@@ -303,3 +303,41 @@ def test_magnitude_outputs_of_the_dropout_gather_and_the_readout_adjoint():
     check(lib().rr_segment_mean_bwd_masked_f32(*args, ptr(d1), H, stream()), "segment_mean_bwd_masked")
     check(lib().rr_segment_mean_bwd_masked_amax_f32(*args, ptr(d2), H, ptr(slot2), stream()), "segment_mean_bwd_masked_amax")
     assert torch.equal(d1, d2) and float(d2.abs().max()) > 0 and float(slot2.max()) == float(d2.abs().max())
+
+
+def test_a_querys_scores_in_two_different_batches(parity_log):
+    """DESIGN.md section 2, H6 ii: with three bf16 terms a query's eval-mode scores are the same bits whatever else is in the
+    batch (every GEMM row is computed on its own); with two f16 terms the operand scale follows the batch's largest magnitude,
+    which reaches elements more than 2^-18 below it - measured here: how far the scores of the same 12 candidates move
+    between a batch of 3 queries and a batch of 40 (H = 300, eval mode, step plans)."""
+    from oracle import ref_cpu as O
+    from reactranker_amd import featurization, synth
+    from tests.test_gpu_model import make_model
+    cfg = dict(hidden_size=300, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
+               ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
+    model = make_model(cfg, synth.seeded_weights(O.model_shapes(300, 3, 3, 3, 1, 1, True), 11)).eval()
+    q1 = synth.make_queries(5, 1, [12], atoms_lo=10, atoms_hi=24)
+    small = synth.make_queries(6, 2, [7, 9], atoms_lo=10, atoms_hi=24)
+    big = synth.make_queries(7, 39, 32, atoms_lo=10, atoms_hi=24)
+
+    def scores(other):
+        r = q1.r_specs + other.r_specs
+        p = q1.p_specs + other.p_specs
+        add = torch.cat([torch.tensor(q1.add_features), torch.tensor(other.add_features)]).numpy()
+        rb, pb = featurization.BatchMolGraph(r, K=4), featurization.BatchMolGraph(p, K=4)
+        with torch.no_grad():
+            return model(rb, pb, gpu=0, add_features=add)[:12].clone()
+    old = Fn.SplitGemm.f16
+    try:
+        Fn.SplitGemm.f16 = False
+        a3, b3 = scores(small), scores(big)
+        Fn.SplitGemm.f16 = True
+        a2, b2 = scores(small), scores(big)
+    finally:
+        Fn.SplitGemm.f16 = old
+    d3 = float((a3 - b3).abs().max())
+    d2 = float(((a2 - b2).abs() / (1 + a2.abs())).max())
+    parity_log(f"the same 12 candidates in a batch of 3 and of 40 queries: three bf16 terms max |score difference| {d3:.1e}; "
+               f"two f16 terms {d2:.2e} of (1 + |score|); identical candidate order {bool(torch.equal(a2.argsort(), b2.argsort()))}")
+    assert d3 == 0.0
+    assert d2 <= 1e-6 and torch.equal(a2.argsort(), b2.argsort())
