@@ -1,6 +1,7 @@
 """Two-term f16 split GEMM (w_packed = 3: 3 MFMAs per k-step) next to the three-term bf16 one (w_packed = 2: 6 MFMAs) and the
 exact-f32 MFMA GEMM on the same inputs: error against f64 and time, for the plain, masked-dX and gathered forward forms.
-Usage (GPU box): RR_LIB_PATH=build/variants/lib_f16.so python tools/f16_gemm_bench.py"""
+The operand bounds (magnitude slots) are found once outside the timing loops, as the step plans get them from the producing kernels.
+Usage (GPU box): python tools/f16_gemm_bench.py        (RR_LIB_PATH=build/variants/lib_X.so times a variant build)"""
 import sys, os, ctypes as C, torch
 sys.path.insert(0, os.getcwd())
 from reactranker_amd import functions as Fn
