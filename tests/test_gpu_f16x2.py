@@ -341,3 +341,31 @@ def test_a_querys_scores_in_two_different_batches(parity_log):
                f"two f16 terms {d2:.2e} of (1 + |score|); identical candidate order {bool(torch.equal(a2.argsort(), b2.argsort()))}")
     assert d3 == 0.0
     assert d2 <= 1e-6 and torch.equal(a2.argsort(), b2.argsort())
+
+
+@pytest.mark.parametrize("p,train", [(0.1, True), (0.0, False)])
+def test_two_term_plans_do_not_depend_on_the_stream_layout(p, train):
+    """the magnitude slots are filled on whichever stream produces or first consumes a tensor and read on others: with the
+    side / aux streams off, and with the reactant encoder's backward forked onto the aux stream (RR_PLAN_AUX_BACKWARD: both
+    passes read bounds found before the fork), scores, loss and every gradient must be the same bits as by default"""
+    from oracle import ref_cpu as O
+    from reactranker_amd import featurization, synth
+    from tests.test_gpu_model import make_model
+    from tests.test_gpu_plan import _run, _same
+    cfg = dict(hidden_size=64, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
+               ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
+    model = make_model(cfg, synth.seeded_weights(O.model_shapes(64, 3, 3, 3, 1, 1, True), 5), dropout=p)
+    model = model.train() if train else model.eval()
+    qb = synth.make_queries(23, 5, [7, 3, 9, 5, 6], atoms_lo=5, atoms_hi=14)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    old = (Fn.SplitGemm.f16, Fn.SideStream.enabled, Fn.AuxStream.enabled, Fn.AuxStream.backward)
+    try:
+        Fn.SplitGemm.f16 = True
+        a = _run(model, rb, pb, qb, 99, plan=True)
+        Fn.SideStream.enabled = Fn.AuxStream.enabled = False
+        _same(a, _run(model, rb, pb, qb, 99, plan=True))
+        Fn.SideStream.enabled = Fn.AuxStream.enabled = True
+        Fn.AuxStream.backward = True
+        _same(a, _run(model, rb, pb, qb, 99, plan=True))
+    finally:
+        Fn.SplitGemm.f16, Fn.SideStream.enabled, Fn.AuxStream.enabled, Fn.AuxStream.backward = old
