@@ -369,3 +369,128 @@ def test_two_term_plans_do_not_depend_on_the_stream_layout(p, train):
         _same(a, _run(model, rb, pb, qb, 99, plan=True))
     finally:
         Fn.SplitGemm.f16, Fn.SideStream.enabled, Fn.AuxStream.enabled, Fn.AuxStream.backward = old
+
+
+def test_linear_f16x2_random_shapes_against_f64(parity_log):
+    """a seeded sweep over output widths 4 .. 608, one or two operand segments of odd widths, row counts 1 .. 30,000, with and
+    without gather / subtract / bias / residual / ReLU: every kernel geometry (<4,4,8>, <10,10,8>, <19,5,8>, <19,19,12> one-block
+    and persistent, <38,19,12>), partial last k-steps and column tiles, the weight image's trailer - against f64"""
+    import numpy as np
+    rng = np.random.default_rng(20260)
+    worst, n_cases = 0.0, 0
+    for case in range(48):
+        N = int(rng.choice([4, 8, 32, 60, 64, 68, 128, 160, 164, 300, 304, 308, 600, 608]))
+        K1 = int(rng.integers(1, 420))
+        K2 = int(rng.choice([0, 0, int(rng.integers(1, 200))]))
+        M = int(rng.choice([1, 15, 16, 17, 191, 193, 4000, 8192, 8193, int(rng.integers(9000, 30000))]))
+        gather = bool(rng.integers(0, 2)) and M > 16
+        sub = gather and bool(rng.integers(0, 2))
+        relu, resid, bias = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        xs, ws = float(10.0 ** rng.integers(-6, 4)), float(10.0 ** rng.integers(-3, 3))
+        torch.manual_seed(case)
+        K = K1 + K2
+        W = torch.randn(N, K, device=dev) / K ** 0.5 * ws
+        nsrc = M // 2 + 3 if gather else M
+        x1 = torch.randn(nsrc, (K1 + 3) // 4 * 4, device=dev) * xs
+        kw = dict(a1=x1, k1=K1)
+        A1 = x1[:, :K1]
+        if gather:
+            idx = torch.randint(0, nsrc, (M,), device=dev, dtype=torch.int32)
+            idx[0] = -1
+            kw["a1_idx"] = idx
+            A1 = torch.where(idx[:, None] >= 0, x1[idx.clamp(min=0).long(), :K1], torch.zeros(1, device=dev))
+            if sub:
+                xsub = torch.randn(M, (K1 + 3) // 4 * 4, device=dev) * xs
+                sidx = torch.randint(0, M, (M,), device=dev, dtype=torch.int32)
+                kw.update(a1_sub=xsub, a1_sub_idx=sidx)
+                A1 = A1 - xsub[sidx.long(), :K1]
+        X = A1
+        if K2:
+            x2 = torch.randn(M, (K2 + 3) // 4 * 4, device=dev) * xs * 0.5
+            kw.update(a2=x2, k2=K2)
+            X = torch.cat([A1, x2[:, :K2]], 1)
+        b = torch.randn(N, device=dev) * xs * ws if bias else None
+        res = torch.randn(M, N, device=dev) * xs * ws if resid else None
+        if bias:
+            kw["bias"] = b
+        if resid:
+            kw["residual"] = res
+        if relu:
+            kw["act"] = Fn.ACT_RELU
+        wh = _pack(W, 0, N, 0, K1, K2, 2)
+        out = Fn.linear(M, N, wh, **kw)
+        ref = X.double() @ W.double().t()
+        den = X.double().abs() @ W.double().abs().t() + 2.0 ** -36 * float(X.abs().max()) * W.double().abs().sum(1)[None, :] * 1e6
+        if bias:
+            ref = ref + b.double()
+            den = den + b.double().abs()
+        if resid:
+            ref = ref + res.double()
+            den = den + res.double().abs()
+        if relu:
+            ref = torch.relu(ref)
+        e = _rel(out, ref, den + 1e-300)
+        worst = max(worst, e)
+        n_cases += 1
+        assert e <= 2e-6, (case, M, N, K1, K2, gather, sub, relu, resid, bias, xs, ws, e)
+    parity_log(f"{n_cases} random shapes (N 4..608, K1 1..419, K2 0..199, M 1..30,000, gather / subtract / bias / residual / ReLU): worst max err {worst:.2e}")
+
+
+def test_wgrad_f16x2_random_shapes_against_f64(parity_log):
+    """the same sweep for the weight gradient (rr_wgrad_args.split = 2): N 4..600, one or two X segments of odd widths (all three
+    k-block widths), 1 .. 40,000 rows, gathered / subtracted X, masked dZ; dW and dbias against f64"""
+    import numpy as np
+    rng = np.random.default_rng(777)
+    old_min, old_f16 = Fn.SPLIT_MIN_ROWS, Fn.SplitGemm.f16
+    Fn.SPLIT_MIN_ROWS, Fn.SplitGemm.f16 = 1, True
+    worst = 0.0
+    try:
+        for case in range(32):
+            N = int(rng.choice([4, 32, 64, 160, 164, 300, 600]))
+            K1 = int(rng.integers(1, 400))
+            K2 = int(rng.choice([0, 0, int(rng.integers(1, 160))]))
+            M = int(rng.choice([1, 31, 33, 500, 8192, int(rng.integers(9000, 40000))]))
+            gather = bool(rng.integers(0, 2)) and M > 40
+            sub = gather and bool(rng.integers(0, 2))
+            mask = bool(rng.integers(0, 2))
+            zs, xs = float(10.0 ** rng.integers(-7, 2)), float(10.0 ** rng.integers(-3, 3))
+            torch.manual_seed(1000 + case)
+            dz = torch.randn(M, N, device=dev) * zs
+            nsrc = M // 2 + 3 if gather else M
+            x1 = torch.randn(nsrc, (K1 + 3) // 4 * 4, device=dev) * xs
+            kw = dict(x1=x1, k1=K1)
+            X1 = x1[:, :K1]
+            if gather:
+                idx = torch.randint(0, nsrc, (M,), device=dev, dtype=torch.int32)
+                kw["x1_idx"] = idx
+                X1 = x1[idx.long(), :K1]
+                if sub:
+                    xsub = torch.randn(M, (K1 + 3) // 4 * 4, device=dev) * xs
+                    sidx = torch.randint(0, M, (M,), device=dev, dtype=torch.int32)
+                    kw.update(x1_sub=xsub, x1_sub_idx=sidx)
+                    X1 = X1 - xsub[sidx.long(), :K1]
+            X = X1
+            if K2:
+                x2 = torch.randn(M, (K2 + 3) // 4 * 4, device=dev) * xs * 3
+                kw.update(x2=x2, k2=K2)
+                X = torch.cat([X1, x2[:, :K2]], 1)
+            dzr = dz
+            if mask:
+                y = torch.randn(M, N, device=dev)
+                kw.update(mask=y, mask_scale=1.25)
+                dzr = torch.where(y > 0, dz * 1.25, torch.zeros_like(dz))
+            dw = torch.zeros(N, K1 + K2, device=dev)
+            db = torch.zeros(N, device=dev)
+            Fn.wgrad(M, N, dz, dw, dbias=db, **kw)
+            ref = dzr.double().t() @ X.double()
+            # (the contract's absolute floor: 2^-40 of each operand tensor's largest magnitude per product, M products per entry)
+            floor = 2.0 ** -36 * M * float(dzr.abs().max()) * max(float(X.abs().max()), 1.0)
+            den = dzr.double().abs().t() @ X.double().abs() + floor + 1e-300
+            rb = dzr.double().sum(0)
+            dbn = dzr.double().abs().sum(0) + floor + 1e-300
+            e = max(_rel(dw, ref, den), _rel(db, rb, dbn))
+            worst = max(worst, e)
+            assert e <= 3e-6, (case, M, N, K1, K2, gather, sub, mask, zs, xs, e)
+    finally:
+        Fn.SPLIT_MIN_ROWS, Fn.SplitGemm.f16 = old_min, old_f16
+    parity_log(f"32 random weight-gradient shapes (N 4..600, K1 1..399, K2 0..159, M 1..40,000, gather / subtract / mask): worst max err {worst:.2e}")
