@@ -9,24 +9,28 @@ gradient all-reduce (N > 1) + Adam/NoamLR.  Graphs are pre-packed and resident i
 of distinct steps is cycled so no step's activations stay in the 256 MiB Infinity Cache between uses.
 
     python bench.py --gpus 1 --steps 30 --warmup 5
+    python bench.py --gpus N ...          (N > 1 without a launcher: starts `python -m torch.distributed.run` itself as a child)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement): value = whole-job queries/s of the headline preset.
-Extra objects in the same line:
-  roofline / roofline_gather (+ _isolated)  dominant MFMA kernel and the gather kernel, live HIP-event timing
-  cpu_baseline                              the CPU oracle on this box's host cores (rank 0 / N=1 only, bounded sample)
-  epoch_stream                              the same training step fed from a shard file on disk through the pinned /
-                                            copy-stream prefetcher (reactranker_amd.shards) over >= 200 DISTINCT steps
-  presets                                   the other BASELINE configurations at full step size (ListNet 64 x 32,
-                                            RankNet 256 x 64 = 1,032,192 ordered pairs, UC-Listwise hidden 600 depth 6),
-                                            each with its own queries/s and roofline
-  dp                                        (N > 1) the ranks RCCL saw and the all-reduce's duration from HIP events
+Rank 0 prints ONE JSON line of at most 6 KB (contract in the task statement; tests/test_bench_line_cpu.py holds the size and
+the keys): value = whole-job queries/s of the headline preset in the library's DEFAULT arithmetic - f32 in / out /
+accumulate, every encoder multiply through three exact bf16 terms per operand (no operand bit dropped).  In the line:
+  roofline / roofline_gather   dominant MFMA kernel and the gather kernel, live HIP-event timing in situ
+  cpu_baseline                 the CPU oracle on this box's host cores (rank 0 / N=1 only, bounded sample)
+  f32_mfma_path, f16x2_path    the same steps with every GEMM on the f32 MFMA / on the opt-in two-f16-term form (own dtype string)
+  epoch_stream                 the same training step fed from shard files on disk over >= 200 DISTINCT steps
+  presets                      the other BASELINE configurations at full step size: queries/s and ms/step each
+  dp                           (N > 1) the ranks RCCL saw and the all-reduce's duration from HIP events
+Everything else - per-kernel tables, isolated rooflines, the eval path's roofline, notes - goes to bench_detail.json (next to
+this file and, when it exists, gpurun_out/) and to stderr.
 """
 import argparse
 import hashlib
 import json
 import os
 import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -43,6 +47,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 SPLIT_PRODUCTS = 6                # bf16 MFMA products issued per f32 multiply on the three-term split path
 F16X2_PRODUCTS = 3                # f16 MFMA products per multiply on the two-term path (same 2.5 PF dense peak)
+DTYPE_BF16X3 = "f32"              # f32 in / out / accumulate; every operand bit enters the products (three exact bf16 terms)
+DTYPE_F16X2 = "f32 io, 2xf16 22-bit operands"   # the opt-in two-term form rounds operands to 22 bits: not an f32 claim
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 PRESETS = {
@@ -373,6 +379,133 @@ def cpu_baseline(args, cfg, qb0):
                f"with the {nq}-query figures")
     return vec
 
+# ------------------------------------------------------------------------------------------------ the one JSON line
+LINE_LIMIT = 6144          # bytes; the driver's capture truncated round 4's 21.5 KB line from the FRONT (metric, value, ... lost)
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches",
+             "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "traffic")
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _pick(d, keys):
+    return None if not d else {k: d[k] for k in keys if k in d}
+
+
+def compact_line(full: dict) -> dict:
+    """The driver-facing line: the contract's keys + roofline + cpu_baseline + one number per comparison leg.  `full` is
+    everything bench.py measured (it goes to bench_detail.json)."""
+    roof = _pick(full.get("roofline"), ROOF_KEYS)
+    if roof is not None:
+        fr = full["roofline"]
+        mv = fr.get("mfma") or {}
+        if mv:                                            # the split GEMM's other view, three numbers
+            roof["f32_equivalent_tflops"] = mv.get("f32_equivalent_tflops")
+            roof["issued_tflops"] = mv.get("issued_bf16_tflops")
+            roof["products_per_multiply"] = mv.get("products_per_multiply")
+        if fr.get("hbm"):
+            roof["algorithmic_gbs"] = fr["hbm"].get("algorithmic_gbs")
+        roof["traffic_source"] = fr.get("traffic_source")
+    rg = _pick(full.get("roofline_gather"), ROOF_KEYS)
+    cpu = _pick(full.get("cpu_baseline"), ("value", "unit", "cores", "kind", "sample"))
+    if cpu and isinstance(cpu.get("sample"), str) and len(cpu["sample"]) > 220:
+        cpu["sample"] = cpu["sample"][:217] + "..."
+
+    def leg(d, extra=()):
+        return _pick(d, ("queries_per_s", "ms_per_step") + tuple(extra))
+    ep = full.get("epoch_stream")
+    if ep and "skipped" in ep:
+        ep_c = {"skipped": str(ep["skipped"])[:120]}
+    else:
+        ep_c = None if not ep else {"queries_per_s": ep.get("epoch_queries_per_s"), "vs_resident": ep.get("vs_resident"),
+                                    "distinct_steps": ep.get("distinct_steps"), "ms_per_step": ep.get("ms_per_step")}
+    pre = None
+    if full.get("presets"):
+        pre = {k: ({"error": str(v["error"])[:100]} if "error" in v else {"value": v.get("value"), "ms_per_step": v.get("ms_per_step")})
+               for k, v in full["presets"].items()}
+    dp = full.get("dp")
+    dp_c = None
+    if dp:
+        dp_c = {"backend": dp.get("backend"), "bucket_bytes": dp.get("bucket_bytes"), "allreduce_us": dp.get("allreduce_us"),
+                "rccl_ranks": [{"rank": r.get("rank"), "device": r.get("device"), "uuid": str(r.get("uuid", ""))[:18]}
+                               for r in dp.get("rccl_ranks", [])]}
+    val = full.get("validation") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data", "gemm_arithmetic", "config", "step_ms")}
+    line.update({"roofline": roof, "roofline_gather": rg, "cpu_baseline": cpu, "gpu_over_cpu": full.get("gpu_over_cpu"),
+                 "f32_mfma_path": leg(full.get("f32_mfma_path")),
+                 "epoch_stream": ep_c, "presets": pre, "fwd_loss_queries_per_s": full.get("fwd_loss_queries_per_s"),
+                 "validation_queries_per_s": val.get("queries_per_s"), "dp": dp_c, "final_loss": full.get("final_loss"),
+                 "detail": full.get("detail")})
+    for k in ("f16x2_path", "bf16x3_path"):              # the OTHER split arithmetic, with its own dtype string
+        if full.get(k):
+            line[k] = leg(full[k], ("dtype",))
+    return line
+
+
+def emit(full: dict) -> str:
+    """Write the detail file(s), print the details to stderr and return the compact line as a string <= LINE_LIMIT bytes."""
+    paths = [os.path.join(REPO, "bench_detail.json")]
+    if os.path.isdir(os.path.join(REPO, "gpurun_out")):
+        paths.append(os.path.join(REPO, "gpurun_out", "bench_detail.json"))
+    written = []
+    for q in paths:
+        try:
+            with open(q, "w") as f:
+                json.dump(full, f, indent=1)
+            written.append(os.path.relpath(q, REPO))
+        except OSError as e:                              # read-only checkout: the details still go to stderr
+            log(f"could not write {q}: {e}")
+    full["detail"] = written[0] if written else None
+    line = compact_line(full)
+    out = json.dumps(line, separators=(",", ":"))
+    for drop in ("validation_queries_per_s", "fwd_loss_queries_per_s", "step_ms", "gemm_arithmetic", "presets", "epoch_stream"):
+        if len(out.encode()) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)                              # (never reached at the sizes tested; the contract's keys go last)
+        out = json.dumps(line, separators=(",", ":"))
+    for k in ("kernels", "kernels_isolated", "kernels_fwd", "roofline_isolated", "roofline_gather_isolated", "roofline_fwd",
+              "roofline_fwd_gather", "validation", "host_prep_s"):
+        if full.get(k) is not None:
+            log(f"detail {k}: " + json.dumps(full[k]))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 without a launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start `python -m torch.distributed.run` as a CHILD process
+    (one rank per GPU; no exec, and this parent has not touched the GPU), relay rank 0's JSON line and return the child's exit
+    code.  Matches how the reference is launched on several GPUs (main_ranknet.py:143-160, main.py:145-161: one process per
+    device); the driver's own `torch.distributed.run ... bench.py --gpus N` never comes through here (WORLD_SIZE is set)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    log(f"--gpus {n} without a launcher: starting {n} ranks through torch.distributed.run")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:                                # rank 0's line; anything else the ranks print to stdout goes to stderr
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("the ranks exited 0 without printing a result line")
+        rc = 1
+    return rc
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -396,20 +529,25 @@ def main():
     ap.add_argument("--no-epoch", action="store_true", help="skip the streamed-from-disk epoch leg")
     ap.add_argument("--epoch-steps", type=int, default=200, help="DISTINCT packed steps written to shard files and streamed")
     ap.add_argument("--shard-workers", type=int, default=8, help="CPU processes packing the shard files")
-    ap.add_argument("--no-f32-path", action="store_true", help="skip the exact-f32-MFMA comparison leg")
+    ap.add_argument("--no-f32-path", action="store_true", help="skip the exact-f32-MFMA and other-split-arithmetic comparison legs")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="ONLY the timed region on the step plans (no per-op event passes, comparison legs, presets, epoch leg or CPU "
+                         "baseline): what a rocprofv3 --kernel-trace --stats run should profile, so its percentages are a training step's")
     ap.add_argument("--no-side-stream", action="store_true", help="run weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-aux-stream", action="store_true", help="run the reactant encoder on the main stream")
     ap.add_argument("--aux-backward", action="store_true", help="also run the reactant encoder's backward on the aux stream")
     ap.add_argument("--foreach-adam", action="store_true", help="torch's multi-kernel Adam instead of the library's one-launch Adam")
     ap.add_argument("--torch-fused-adam", action="store_true", help="torch's fused Adam instead of the library's one-launch Adam")
     args = ap.parse_args()
+    if args.plan_only:
+        args.no_profile = args.no_fwd_only = args.no_presets = args.no_epoch = args.no_f32_path = args.no_cpu_baseline = True
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:   # BEFORE any torch.cuda call: the parent never touches the GPU
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
         args.gpus = world
     cfg = dict(PRESETS[args.config])
     for k, v in (("queries", args.queries_per_step), ("cands", args.cands), ("hidden", args.hidden), ("depth", args.depth),
@@ -635,14 +773,16 @@ def main():
                             ms_per_step=round(float(t32.item()) / n32 * 1e3, 3), steps=n32, step_ms=step_stats(per32),
                             note="same model state, same steps, SplitGemm.enabled = False (RR_PLAN_F32_GEMM): every GEMM on "
                                  "v_mfma_f32_16x16x4_f32; `value` above is the " +
-                                 ("two-f16-term path" if Fn.SplitGemm.f16 else "three-bf16-term path"))
+                                 ("two-f16-term path" if Fn.SplitGemm.f16 else "three-exact-bf16-term path"))
         finally:
             Fn.SplitGemm.enabled = True
         log(f"f32-MFMA path: {f32_path}")
-    # ---- ... and with three exact bf16 terms per operand (six products: every operand bit kept) where `value` runs two f16 terms
-    bf16x3_path = None
-    if not args.no_f32_path and Fn.SplitGemm.f16:
-        Fn.SplitGemm.f16 = False
+    # ---- ... and on the OTHER split arithmetic: the opt-in two-f16-term form beside the default three-exact-bf16-term headline
+    # (or the other way round when RR_F16X2=1 made two terms this run's arithmetic)
+    other_path, other_key = None, ("bf16x3_path" if Fn.SplitGemm.f16 else "f16x2_path")
+    if not args.no_f32_path:
+        f16_was = Fn.SplitGemm.f16
+        Fn.SplitGemm.f16 = not f16_was
         try:
             for i in range(3):
                 R.train_step(pool[i % len(pool)])
@@ -651,14 +791,17 @@ def main():
             t3 = torch.tensor([s3], dtype=torch.float64, device=device)
             if world > 1:
                 dist.all_reduce(t3, op=dist.ReduceOp.MAX)
-            bf16x3_path = dict(queries_per_s=round(world * n3 * cfg["queries"] / float(t3.item()), 2),
-                               ms_per_step=round(float(t3.item()) / n3 * 1e3, 3), steps=n3, step_ms=step_stats(per3),
-                               note="same model state, same steps, SplitGemm.f16 = False: encoder GEMMs and weight gradients on "
-                                    "three exact bf16 terms per operand (6 x v_mfma_f32_16x16x32_bf16 per k-step; rounds 2-4's "
-                                    "headline path); `value` above runs two f16 terms (3 x v_mfma_f32_16x16x32_f16)")
+            other_path = dict(queries_per_s=round(world * n3 * cfg["queries"] / float(t3.item()), 2),
+                              ms_per_step=round(float(t3.item()) / n3 * 1e3, 3), steps=n3, step_ms=step_stats(per3),
+                              dtype=DTYPE_BF16X3 if f16_was else DTYPE_F16X2,
+                              note="same model state, same steps, SplitGemm.f16 = " + str(not f16_was) + ": encoder GEMMs and weight "
+                                   "gradients on " + ("three exact bf16 terms per operand (6 x v_mfma_f32_16x16x32_bf16 per k-step)"
+                                                      if f16_was else
+                                                      "two f16 terms per operand scaled per tensor (3 x v_mfma_f32_16x16x32_f16 per k-step; "
+                                                      "22-bit operands, batch-dependent below 2^-40 of a tensor's largest magnitude: opt-in)"))
         finally:
-            Fn.SplitGemm.f16 = True
-        log(f"three-bf16-term path: {bf16x3_path}")
+            Fn.SplitGemm.f16 = f16_was
+        log(f"{other_key}: {other_path}")
 
     # ---- streamed epoch: the SAME training step fed from shard files on disk
     epoch = None
@@ -776,20 +919,15 @@ def main():
     if rank == 0:
         qps = world * args.steps * cfg["queries"] / elapsed
         g0 = pool[0]["p"].device_graph(device)
-        line = {
+        full = {
             "metric": cfg["metric"], "value": round(qps, 2), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gemm_arithmetic": ("f32 in / f32 out / f32 accumulate; encoder GEMMs and weight gradients (rows = atoms / bonds) multiply "
-                                "through two f16 terms per operand, scaled per tensor by a power of two (22 significant bits; three "
-                                "v_mfma_f32_16x16x32_f16 per k-step) - measured error against f64 at the f32 MFMA chain's level "
-                                "(tests/test_gpu_f16x2.py), every parity test passes in this mode and in the three-exact-bf16-term mode "
-                                "(`bf16x3_path`: six products, no operand bit dropped); the FFN head stays on v_mfma_f32_16x16x4_f32"
-                                if Fn.SplitGemm.f16 else
-                                "f32 in / f32 out / f32 accumulate; encoder GEMMs (rows = atoms / bonds) multiply through three "
-                                "exact bf16 terms per operand on the bf16 matrix core - measured error against f64 at or below "
-                                "the f32 MFMA chain (tests/test_gpu_split.py); the FFN head stays on v_mfma_f32_16x16x4_f32"),
+            "vs_baseline": None, "dtype": DTYPE_F16X2 if Fn.SplitGemm.f16 else DTYPE_BF16X3, "data": "synthetic",
+            "gemm_arithmetic": ("f32 in/out/accumulate; encoder GEMMs via two f16 terms per operand scaled per tensor (22-bit operands, "
+                                "3 MFMA products); FFN head on the f32 MFMA" if Fn.SplitGemm.f16 else
+                                "f32 in/out/accumulate; encoder GEMMs via three EXACT bf16 terms per operand (no operand bit dropped, "
+                                "6 MFMA products); FFN head on the f32 MFMA"),
             "config": {"workload": f"{cfg['workload']}, {cfg['queries']}-query steps, D-MPNN depth={cfg['depth']} "
                                    f"hidden={cfg['hidden']}",
                        "preset": args.config,
@@ -797,19 +935,18 @@ def main():
                        "queries_per_step_per_gpu": cfg["queries"], "candidates_per_query": cfg["cands"],
                        "atoms_per_step_side": int(g0.nA), "directed_bonds_per_step_side": int(g0.nB),
                        "pad_width_K": int(g0.K), "dropout": cfg["dropout"], "step_pool": len(pool),
-                       "parallelism": f"dp{world} (whole queries per rank, one RCCL all-reduce of the flat fp32 "
-                                      f"gradient bucket per step)"},
-            "step_ms": step_stats(per_ms),
+                       "parallelism": f"dp{world}"},
+            "step_ms": {k: v for k, v in step_stats(per_ms).items() if k != "note"},
             "roofline": roof, "roofline_gather": roof_g, "roofline_isolated": roof_iso,
             "roofline_gather_isolated": roof_g_iso, "cpu_baseline": cpu,
-            "f32_mfma_path": f32_path, "bf16x3_path": bf16x3_path, "epoch_stream": epoch, "presets": presets or None, "dp": dp_info,
+            "f32_mfma_path": f32_path, other_key: other_path, "epoch_stream": epoch, "presets": presets or None, "dp": dp_info,
             "kernels": ktable, "kernels_isolated": ktable_iso, "final_loss": round(loss_val, 6),
             "host_prep_s": {"synthetic_generation": round(R.t_gen, 2), "native_pack_and_upload": round(R.t_pack, 2)},
         }
-        line.update(extra)
+        full.update(extra)
         if cpu:
-            line["gpu_over_cpu"] = round(qps / cpu["value"], 1)
-        print(json.dumps(line))
+            full["gpu_over_cpu"] = round(qps / cpu["value"], 1)
+        print(emit(full), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

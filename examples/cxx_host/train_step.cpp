@@ -160,10 +160,11 @@ int main(int argc, char** argv) {
   if (s.workspace_bytes == 0) { fprintf(stderr, "rr_reaction_workspace_bytes rejected the step\n"); return 4; }
   s.workspace = dmalloc<uint8_t>(s.workspace_bytes);
 
-  // plan flags: the two-f16-term GEMMs (half the matrix instructions of the three-bf16-term form; the plans find every operand's
-  // magnitude themselves) unless RR_CXX_PLAN_FLAGS says otherwise; forward and backward of a step get the same flags
+  // plan flags: 0 = the three-exact-bf16-term GEMMs (no operand bit dropped, batch-independent scores) unless RR_CXX_PLAN_FLAGS
+  // says otherwise (32 = RR_PLAN_F16X2_GEMM: two f16 terms per operand, half the matrix instructions, 22-bit operands scaled
+  // per tensor - opt-in); forward and backward of a step get the same flags
   const char* fl_env = getenv("RR_CXX_PLAN_FLAGS");
-  const int plan_flags = fl_env != nullptr ? atoi(fl_env) : RR_PLAN_F16X2_GEMM;
+  const int plan_flags = fl_env != nullptr ? atoi(fl_env) : 0;
   RR_OK_(rr_reaction_forward(&m, &s, plan_flags, st));
   // ListMLE over the step's queries (scores = first output column)
   std::vector<int32_t> seg(Q + 1, 0);

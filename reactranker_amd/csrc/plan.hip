@@ -165,6 +165,19 @@ float* amax_claim(Ctx& c, const float* t) {
   return nullptr;
 }
 
+// A tensor that is about to be modified IN PLACE by a kernel without a magnitude output (axpby, the accumulating ReLU
+// backward): a slot claimed before that write would bound only what the producer stored - the f16 scale leaves 2x-4x of
+// headroom, beyond it the split overflows to inf / NaN.  Such a tensor must reach its consumers WITHOUT a slot, so that
+// amax_of() runs its pass after the last write; a plan that violates this fails here instead of training on a stale bound.
+void inplace_write(Ctx& c, const float* t) {
+  if (!c.f16 || t == nullptr || c.ar.base == nullptr) return;
+  for (int i = 0; i < c.ntr; ++i) {
+    if (c.tr[i].p != t || c.tr[i].amax == nullptr) continue;
+    if (getenv("RR_PLAN_DEBUG")) fprintf(stderr, "[rr plan] in-place write to %p after its magnitude slot was claimed\n", static_cast<const void*>(t));
+    c.fail(RR_ERR_ARG);
+  }
+}
+
 void flush_packs(Ctx& c, hipStream_t st) {
   if (c.npq > 0) RR_TRY(c, rr_pack_weights_f32(c.pq, c.npq, st));
   c.npq = 0;
@@ -227,9 +240,11 @@ void set_w(rr_linear_args& a, const Packed& p) {
   if (p.mode < 2) a.a_mask_bits = nullptr;            // only the split GEMM reads sign-bit masks (a_mask stays set)
 }
 
+// claim = false: `out` is modified in place afterwards - no slot is claimed for it (see inplace_write)
 void gather_sum(Ctx& c, const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K, int H,
-                float* out, int64_t ld_out, hipStream_t st, const float* part = nullptr, int64_t n_part = 0, int64_t ld_part = 0) {
-  if (c.f16) RR_TRY(c, rr_gather_sum_amax_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, amax_claim(c, out), st));
+                float* out, int64_t ld_out, hipStream_t st, const float* part = nullptr, int64_t n_part = 0, int64_t ld_part = 0,
+                bool claim = true) {
+  if (c.f16 && claim) RR_TRY(c, rr_gather_sum_amax_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, amax_claim(c, out), st));
   else if (part) RR_TRY(c, rr_gather_sum_padrow_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, st));
   else RR_TRY(c, rr_gather_sum_f32(src, n_src, ld_src, idx, n_out, K, H, out, ld_out, st));
 }
@@ -680,8 +695,11 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
   else
     RR_TRY(c, rr_gather_sum_masked_f32(d_msg, S.msgs[1], g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, ks, dz1_u, H, st));
   float* d_inp_u = c.alloc(gu.nB, H);
+  // d_inp_u is accumulated in place twice below (axpby, the ReLU backward of msg0): its bound for the W_i weight gradient is
+  // found by a pass AFTER the last write (amax_of in wgrad()), never by the gather that writes its first summand
   if (have_full) {
-    gather_sum(c, d_inp_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, d_inp_u, H, st);
+    gather_sum(c, d_inp_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, d_inp_u, H, st, nullptr, 0, 0, /*claim=*/false);
+    inplace_write(c, d_inp_u);
     RR_TRY(c, rr_axpby_f32(1.0f, d_inp_u, 1.0f, dz1_u, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
   } else {
     RR_TRY(c, rr_axpby_f32(1.0f, dz1_u, 0.0f, nullptr, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
@@ -701,6 +719,7 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     lin(c, a, st);
   }
   float* d_msg0_u = bond_adjoint(c, gu, H, d_min_u, part_u, st);
+  inplace_write(c, d_inp_u);
   RR_TRY(c, rr_relu_bwd_f32(d_msg0_u, S.msg0_u, 1.0f, nullptr, d_inp_u, gu.nB * static_cast<int64_t>(H), st));   // msg0 = relu(inp)
   rr_wgrad_args w = WA(gu.nB, H, d_inp_u, H, G.wi, m.enc_wi.in, G.bi, accumulate);
   w.x1 = gu.f_bonds; w.ldx1 = gu.ld_fb; w.k1 = m.bond_fdim;

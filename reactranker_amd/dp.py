@@ -217,6 +217,9 @@ class Exchange:
         """p.grad <- sum over ranks of weight_r * p.grad_r, for every parameter of the model (missing gradients - an
         empty shard, a window without ordered pairs - count as zeros)."""
         if self.on:
+            if self.bucket is None:
+                raise RuntimeError("dp.Exchange.reduce_grads: this Exchange was built without a model (Exchange(None, group)), so it "
+                                   "owns no gradient bucket; construct it as Exchange(model, group) in a data-parallel job")
             self.bucket.allreduce(weight, group=self.group)
 
     def sum(self, t: torch.Tensor) -> torch.Tensor:

@@ -473,14 +473,17 @@ def _grad_like(t):
 
 class SplitGemm:
     """Encoder GEMMs on the bf16 matrix core: every f32 operand is written exactly as three bf16 terms and six
-    products are accumulated in f32 (rr_linear_args.w_packed = 2; error at or below the f32 MFMA chain's).
+    products are accumulated in f32 (rr_linear_args.w_packed = 2; no operand bit is dropped, error at or below the f32 MFMA
+    chain's).  This is the default: a query's scores do not depend on what else is in its batch, and an N-process run
+    reproduces the 1-process run up to the gradient bucket's summation order.
     enabled = False keeps every GEMM on v_mfma_f32_16x16x4_f32.
-    f16 = True (the default; RR_F16X2=0 in the environment turns it off): two f16 terms per operand instead (w_packed = 3,
-    RR_PLAN_F16X2_GEMM): three products, 22 significant bits per operand scaled to its tensor's largest magnitude, measured
-    error at the f32 MFMA chain's level.  The step plans take the operand bounds from the producing kernels; the per-op
-    mirror below finds them with one rr_amax_f32 pass per operand (slower: it exists for tests and per-kernel timing)."""
+    f16 = True (opt-in since round 5; RR_F16X2=1 in the environment turns it on): two f16 terms per operand instead
+    (w_packed = 3, RR_PLAN_F16X2_GEMM): three products, 22 significant bits per operand scaled to its TENSOR's largest
+    magnitude - narrower than f32 operands and batch-dependent below 2^-40 of that magnitude,
+    measured error at the f32 MFMA chain's level.  The step plans take the operand bounds from the producing kernels; the
+    per-op mirror below finds them with one rr_amax_f32 pass per operand (slower: it exists for tests and per-kernel timing)."""
     enabled = True
-    f16 = os.environ.get("RR_F16X2", "1") not in ("", "0")
+    f16 = os.environ.get("RR_F16X2", "0") not in ("", "0")
 
 
 class LinW:

@@ -348,12 +348,12 @@ class StepPrefetcher:
             time.sleep(0.0005)
         # ... and has LANDED: the first DMA out of freshly pinned slots can take tens of milliseconds (measured: 37-95 ms
         # showing up in the first consumer step when only the issue was awaited)
-        try:
-            first = self.ready.queue[0]
-            if first is not None:
-                first[2].synchronize()
-        except IndexError:
-            pass
+        if self._err is not None:                                # the reader died before it staged anything: say so here,
+            raise RuntimeError("shard reader thread failed") from self._err   # not one silent slow step later
+        with self.ready.mutex:                                   # (queue.Queue's own lock: the reader may be appending)
+            first = self.ready.queue[0] if self.ready.queue else None
+        if first is not None and first[2] is not None:
+            first[2].synchronize()
         return time.perf_counter() - t0
 
     def _views(self, slot: int, i: int) -> Dict[str, torch.Tensor]:

@@ -29,7 +29,8 @@ def factorized_training_loop(epoch: int, model, optimizer, scheduler, batches: I
     from .dp import Exchange, step_counts
     if training_algo not in ("sum_session", "accelerate_grad"):
         raise ValueError("training algo {} not implemented".format(training_algo))
-    ex = exchange if exchange is not None else Exchange()
+    own_exchange = exchange is None
+    ex = exchange if exchange is not None else Exchange(model)   # (under torch.distributed it owns the gradient bucket)
     dev = next(model.parameters()).device
     minibatch_loss = []
     for b in batches:
@@ -60,6 +61,8 @@ def factorized_training_loop(epoch: int, model, optimizer, scheduler, batches: I
         optimizer.step()
         scheduler.step()
     model.zero_grad()
+    if own_exchange:
+        ex.close()
     if not minibatch_loss:
         return float("nan")
     per_step = ex.sum(torch.cat(minibatch_loss).double())

@@ -20,10 +20,11 @@ def golden_dir():
 
 
 # ---------------------------------------------------------------------------------------------- GEMM arithmetic of the step plans
-# The whole-step plans run their encoder GEMMs on two f16 terms per operand by default (functions.SplitGemm.f16: 22
-# significant bits, three matrix instructions per k-step) or on three exact bf16 terms (six).  The modules that compare the
-# HIP path with the oracle / the reference's vectors run in BOTH modes; the modules that compare two HIP paths bit for bit
-# (the per-op Python mirror's bounds come from separate passes) are pinned to the three-term form.
+# The whole-step plans run their encoder GEMMs on three exact bf16 terms per operand (six matrix instructions per k-step, no
+# operand bit dropped: the library default since round 5) or, opt-in, on two f16 terms (functions.SplitGemm.f16 / RR_F16X2=1:
+# 22 significant bits scaled per tensor, three instructions).  The modules that compare the HIP path with the oracle / the
+# reference's vectors run in BOTH modes; the modules that compare two HIP paths bit for bit (the per-op Python mirror's
+# bounds come from separate passes) are pinned to the three-term form.
 BOTH_GEMM_MODES = {"test_gpu_model", "test_gpu_headline_kernels", "test_gpu_trainers", "test_gpu_api_parity"}
 DEFAULT_MODE_ONLY = {"test_train_mode_plan_path_above_8192_rows_against_fp64_oracle_h600_d6",
                      "test_train_mode_plan_path_above_8192_rows_against_fp64_oracle_h300"}
@@ -34,10 +35,10 @@ def pytest_generate_tests(metafunc):
     mod = metafunc.module.__name__.rsplit(".", 1)[-1]
     if mod in BOTH_GEMM_MODES and "gemm_mode" in metafunc.fixturenames:
         # (the two train-mode steps above 8,192 rows against the fp64 oracle take 1-2 minutes of CPU time each: the default
-        # arithmetic only - the three-term form at those sizes is held by the GEMM-level tests of the same module, by
+        # arithmetic only - the two-term form at those sizes is held by the GEMM-level tests of the same module, by
         # test_full_step_size_properties and by tests/test_gpu_f16x2.py's plan-against-plan comparison; its measured numbers
-        # from the round's earlier runs stay in profiles/r04_parity_errors.txt)
-        modes = ["f16x2"] if metafunc.function.__name__ in DEFAULT_MODE_ONLY else ["f16x2", "bf16x3"]
+        # from round 4's runs stay in profiles/r04_parity_errors.txt)
+        modes = ["bf16x3"] if metafunc.function.__name__ in DEFAULT_MODE_ONLY else ["bf16x3", "f16x2"]
         metafunc.parametrize("gemm_mode", modes, indirect=True)
 
 

@@ -97,9 +97,9 @@ def test_hidden_size_not_multiple_of_4_matches_oracle(H, depth, p):
     for rep in range(3):                                   # a stream race would show as run-to-run differences
         model.zero_grad()
         out = model(rb, pb, gpu=0, add_features=qb.add_features)
-        close(out, ref, tol=2e-5, what="out")
+        close(out, ref, tol=1e-5, what="out")
         l = RL.MLEloss()(out, scope, targets, 0)
-        close(l, l_ref, tol=2e-5, what="loss")
+        close(l, l_ref, tol=1e-5, what="loss")
         l.sum().backward()
         got = dict(model.named_parameters())
         grads.append({k: got[k].grad.clone() for k in names if got[k].grad is not None})

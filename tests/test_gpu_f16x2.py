@@ -494,3 +494,45 @@ def test_wgrad_f16x2_random_shapes_against_f64(parity_log):
     finally:
         Fn.SPLIT_MIN_ROWS, Fn.SplitGemm.f16 = old_min, old_f16
     parity_log(f"32 random weight-gradient shapes (N 4..600, K1 1..399, K2 0..159, M 1..40,000, gather / subtract / mask): worst max err {worst:.2e}")
+
+
+def test_shared_prefix_input_gradient_bound_follows_its_last_write(parity_log):
+    """Round-4 advice (high): in the shared-prefix backward d_inp_u is written by a gather and then accumulated IN PLACE twice
+    (+ dz1_u, + relu'(msg0) * d_msg0_u); a magnitude slot claimed by the gather would bound the first summand only and the
+    W_i weight gradient's f16 split would overflow (inf / NaN) as soon as the later summands exceed it by the 2x-4x headroom.
+    Here W_h is scaled up so that they exceed it by far more: >= 8,192 distinct-reactant bonds (the weight gradient then runs
+    on the split path), depth 4 (two per-copy layers: the gather path exists), train mode.  The two-term plan must stay
+    finite and agree with the three-term plan (which the other modules hold against the oracle)."""
+    from oracle import ref_cpu as O
+    from reactranker_amd import featurization, synth
+    from tests.test_gpu_model import make_model
+    from tests.test_gpu_plan import _run
+    H, d = 32, 4
+    cfg = dict(hidden_size=H, mpnn_depth=d, mpnn_diff_depth=2, ffn_depth=2, use_bias=True, task_num=1, ffn_last_layer="no_softplus",
+               task_type=None, add_features_dim=1)
+    w = synth.seeded_weights(O.model_shapes(H, d, 2, 2, 1, 1, True), 5)
+    w["encoder.W_h.weight"] = w["encoder.W_h.weight"] * 6.0       # every step back through W_h grows the gradient
+    model = make_model(cfg, w, dropout=0.1).train()
+    nq = 300
+    qb = synth.make_queries(23, nq, 2, atoms_lo=14, atoms_hi=24)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    ub, _, _ = rb.unique()
+    assert ub.n_bonds >= 8192, ub.n_bonds                          # the distinct reactants' W_i gradient takes the split path
+    old = Fn.SplitGemm.f16
+    try:
+        Fn.SplitGemm.f16 = True
+        a = _run(model, rb, pb, qb, 99, plan=True)
+        Fn.SplitGemm.f16 = False
+        b = _run(model, rb, pb, qb, 99, plan=True)
+    finally:
+        Fn.SplitGemm.f16 = old
+    worst = 0.0
+    for k in b[2]:
+        assert torch.isfinite(a[2][k]).all(), k
+        tb = float(b[2][k].abs().max())
+        if tb > 0:
+            worst = max(worst, float((a[2][k] - b[2][k]).abs().max()) / tb)
+    gi = a[2]["encoder.W_i.weight"]
+    parity_log(f"shared prefix, W_h x 6, {ub.n_bonds} distinct bonds: max |dW_i| {float(gi.abs().max()):.3e}; two-term vs three-term "
+               f"gradients, worst / tensor max {worst:.2e}")
+    assert worst <= 5e-5

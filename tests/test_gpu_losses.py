@@ -50,8 +50,8 @@ def test_losses_against_reference_vectors(name, golden_dir):
     assert l.shape == (1,)
     l.sum().backward()
     close(l, L[P + "evid"], what="evid")
-    close(poss.grad[:, 0], L[P + "evid_gs"], tol=2e-5, what="evid_gs")
-    close(poss.grad[:, 1], L[P + "evid_gv"], tol=2e-5, what="evid_gv")
+    close(poss.grad[:, 0], L[P + "evid_gs"], tol=1e-5, what="evid_gs")
+    close(poss.grad[:, 1], L[P + "evid_gv"], tol=1e-5, what="evid_gv")
 
     s = fresh()
     l = RL.MSELoss()(s, targets)
@@ -62,7 +62,7 @@ def test_losses_against_reference_vectors(name, golden_dir):
     v = torch.tensor(L[P + "var"]).cuda().requires_grad_(True)
     l = RL.GaussDisLoss()(s, v, targets, 0)
     l.backward()
-    close(l, L[P + "gauss"]); close(s.grad, L[P + "gauss_gs"]); close(v.grad, L[P + "gauss_gv"], tol=2e-5)
+    close(l, L[P + "gauss"]); close(s.grad, L[P + "gauss_gs"]); close(v.grad, L[P + "gauss_gv"], tol=1e-5)
 
     for sigma in (1.0, 0.5):
         s = fresh()
@@ -118,7 +118,7 @@ def test_losses_against_oracle_random(seed, scope):
     gs_ref, gv_ref = torch.autograd.grad(ref.sum(), [ts, tv])
     poss = torch.stack([torch.tensor(score), torch.tensor(var)], 1).cuda().requires_grad_(True)
     l = RL.evidential_ranking()(poss, scope, tt, None, None, None, 0); l.sum().backward()
-    close(l, ref, tol=2e-5, what="evid")
+    close(l, ref, tol=1e-5, what="evid")
     sc = max(1.0, float(gv_ref.abs().max()))
     close(poss.grad[:, 0], gs_ref, tol=5e-5, what="evid_gs"); close(poss.grad[:, 1] / sc, gv_ref / sc, tol=5e-5, what="evid_gv")
 

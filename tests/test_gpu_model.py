@@ -190,7 +190,7 @@ def test_train_mode_dropout_matches_oracle_with_same_masks(cfgname, p, golden_di
               task_type=cfg["head"], dropout=p)
     ref = O.reaction_forward(P, mc, Hh.golden_graph(d, "r_"), Hh.golden_graph(d, "p_"), add, masks=masks)
     out = model(rb, pb, gpu=0, add_features=add)
-    close(out, ref, tol=2e-5, what="train-mode out")
+    close(out, ref, tol=1e-5, what="train-mode out")
     assert float((out.detach().cpu() - torch.tensor(d["out"])).abs().max()) > 1e-4      # dropout really acted
     if cfg["task_num"] == 1:
         l_ref = O.listmle_loss(ref, scope, targets)
@@ -198,7 +198,7 @@ def test_train_mode_dropout_matches_oracle_with_same_masks(cfgname, p, golden_di
     else:
         l_ref = O.evidential_ranking_loss(ref, scope, targets)
         l = RL.evidential_ranking()(out, scope, targets, None, None, None, 0)
-    close(l, l_ref, tol=2e-5, what="train-mode loss")
+    close(l, l_ref, tol=1e-5, what="train-mode loss")
     names = [k for k in P if P[k].requires_grad]
     g_ref = torch.autograd.grad(l_ref.sum(), [P[k] for k in names], allow_unused=True)
     l.sum().backward()
@@ -370,7 +370,7 @@ def test_full_step_size_properties(name):
                              O.pack_batch(qb.p_specs[sl], K=4), qb.add_features[sl])
     close(out1[sl], ref, what="oracle spot check (scores)")
     close(_loss_of(kind, out1[sl].contiguous(), scope[:n_spot], targets[sl]).sum(),
-          _oracle_loss(kind, ref, scope[:n_spot], targets[sl]).sum(), tol=2e-5, what="oracle spot check (loss)")
+          _oracle_loss(kind, ref, scope[:n_spot], targets[sl]).sum(), tol=1e-5, what="oracle spot check (loss)")
 
 
 @pytest.mark.parametrize("name,cfg,scope,loss_kind", [
@@ -404,7 +404,7 @@ def test_baseline_configs_against_oracle(name, cfg, scope, loss_kind):
     mc = dict(depth=cfg["mpnn_depth"], diff_depth=cfg["mpnn_diff_depth"], ffn_depth=cfg["ffn_depth"], task_type=head)
     ref = O.reaction_forward(P, mc, O.pack_batch(qb.r_specs, K=4), O.pack_batch(qb.p_specs, K=4), qb.add_features)
     out = model(rb, pb, gpu=0, add_features=qb.add_features)
-    close(out, ref, tol=2e-5 if H == 600 else 1e-5, what=name + " out")
+    close(out, ref, tol=1e-5, what=name + " out")
     if loss_kind == "mse":                                # BASELINE configs[0]: the pointwise 'regression' branch
         l, l_ref = RL.MSELoss()(out, targets), O.mse_loss(ref, targets)
     elif loss_kind == "listnet":
@@ -417,7 +417,7 @@ def test_baseline_configs_against_oracle(name, cfg, scope, loss_kind):
         ls_ref, pairs_ref = O.ranknet_sum_session(ref, scope, targets, 1.0)
         assert int(pairs) == int(pairs_ref)
         l, l_ref = ls / pairs, ls_ref / pairs_ref
-    close(l.reshape(-1), l_ref.reshape(-1), tol=2e-5, what=name + " loss")
+    close(l.reshape(-1), l_ref.reshape(-1), tol=1e-5, what=name + " loss")
     names = [k for k in P if P[k].requires_grad]
     g_ref = torch.autograd.grad(l_ref.sum(), [P[k] for k in names], allow_unused=True)
     # fp64 run of the same oracle = ground truth; the fp32 oracle's own distance to it is the noise floor
