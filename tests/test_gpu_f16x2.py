@@ -527,10 +527,11 @@ def test_shared_prefix_input_gradient_bound_follows_its_last_write(parity_log):
     finally:
         Fn.SplitGemm.f16 = old
     worst = 0.0
+    gmax = max(float(v.abs().max()) for v in b[2].values())
     for k in b[2]:
         assert torch.isfinite(a[2][k]).all(), k
         tb = float(b[2][k].abs().max())
-        if tb > 0:
+        if tb > 2e-5 * gmax:                                       # (analytically-zero gradients are noise in both, hazard H5)
             worst = max(worst, float((a[2][k] - b[2][k]).abs().max()) / tb)
     gi = a[2]["encoder.W_i.weight"]
     parity_log(f"shared prefix, W_h x 6, {ub.n_bonds} distinct bonds: max |dW_i| {float(gi.abs().max()):.3e}; two-term vs three-term "
