@@ -38,9 +38,9 @@ def main():
                 os.environ.pop(k, None)
             for k in ks:
                 os.environ[k] = "1"
-            # (Python-side switches: plan flags.)  The two-f16-term GEMMs are the default; "BF16X3" as a knob selects the
-            # three-term form for that variant - or, when some variant names RR_F16X2, only those variants run two terms
-            Fn.SplitGemm.f16 = ("RR_F16X2" in ks) if "RR_F16X2" in knobs else ("BF16X3" not in ks)
+            # (Python-side switches: plan flags.)  Three exact bf16 terms are the default arithmetic (round 5); a variant that
+            # names RR_F16X2 runs the opt-in two-f16-term form
+            Fn.SplitGemm.f16 = "RR_F16X2" in ks
             Fn.SideStream.enabled = "NOSIDE" not in ks
             Fn.AuxStream.enabled = "NOAUX" not in ks
             Fn.AuxStream.backward = "AUXBWD" in ks         # reactant-encoder backward on the aux stream (RR_PLAN_AUX_BACKWARD)
