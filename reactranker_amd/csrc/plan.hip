@@ -73,7 +73,7 @@ int stream_wait(hipStream_t waiter, hipStream_t signaller) {
   // The event orders two streams of ONE device: the producing kernel's own end-of-kernel release and the consumer's acquire
   // (agent scope, as between any two kernels of one stream) already make the data visible, so the marker does not need the
   // system-scope fence a host-visible event carries - its cache writeback / invalidate sits on the RECORDING stream, in front
-  // of that stream's next kernel: 5.0 us per event with the fence, 2.4 us without (tools/scratch/evgap.cpp), ~20 events per
+  // of that stream's next kernel: 5.0 us per event with the fence, 2.4 us without (tools/evgap.cpp), ~20 events per
   // training step, -0.9 % on the step (profiles/r05_experiments.txt item 1).  RR_EV_FENCE=1 restores the default event.
   unsigned fl = hipEventDisableTiming;
   if (!getenv("RR_EV_FENCE")) fl |= hipEventDisableSystemFence;
