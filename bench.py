@@ -172,7 +172,7 @@ class Runner:
         out = self.model(b["r"], b["p"], gpu=self.local, add_features=b["add"])
         loss = self.loss(out, b)
         self.opt.zero_grad(set_to_none=True)
-        loss.sum().backward()
+        self.RL.backward(loss)                            # loss.backward() (train_listwise.py:288) with the constant-one seed
         self.bucket.allreduce(1.0 / self.world)           # equal shards: mean of per-rank normalised grads
         self.sched.step()                                 # NoamLR writes param_groups[0]['lr'] (train/utils.py:88)
         self.opt.step()

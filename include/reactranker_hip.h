@@ -421,6 +421,22 @@ int rr_listmle_bwd_f32(const float* score, int64_t score_stride, const float* ta
                        const int32_t* seg_off, int Q, int max_len, const float* gloss,
                        float* dscore, int64_t dscore_stride, rr_stream_t stream);
 
+/* Fused loss + gradient ("step") forms, ABI revision 8: ONE launch writes `loss` AND d loss / d score for an upstream
+ * gradient of one - what `loss.backward()` feeds a loss that is the root of the graph (train/train_listwise.py:287-288) -
+ * so a training step needs no second loss kernel, no separate reduction launch and no device-side gradient seed.  `loss`,
+ * `partial` and `dscore` hold the bits rr_*_fwd_f32 / rr_*_bwd_f32 (with *gloss == 1.0f) write: same operations in the same
+ * order, the per-query partials summed in the same fixed order by the workgroup that finishes last.  `counter` is ONE
+ * zero-initialised device word per concurrent launch that the caller keeps; the kernel leaves it at zero. */
+int rr_listmle_step_f32(const float* score, int64_t score_stride, const float* targets,
+                        const int32_t* seg_off, int Q, int max_len, float* loss, float* partial /* [Q] */,
+                        unsigned int* counter, float* dscore, int64_t dscore_stride, rr_stream_t stream);
+int rr_listnet_step_f32(const float* score, int64_t score_stride, const float* targets,
+                        const int32_t* seg_off, int Q, int max_len, int64_t total, float* loss, float* partial,
+                        unsigned int* counter, float* dscore, int64_t dscore_stride, rr_stream_t stream);
+int rr_evidential_ranking_step_f32(const float* mu, const float* var, int64_t stride, const float* targets,
+                                   const int32_t* seg_off, int Q, int max_len, float* loss, float* partial,
+                                   unsigned int* counter, float* dmu, float* dvar, int64_t dstride, rr_stream_t stream);
+
 /* ListNet top-1, one global mean over all candidates (train/loss.py:327-352). */
 int rr_listnet_fwd_f32(const float* score, int64_t score_stride, const float* targets,
                        const int32_t* seg_off, int Q, int max_len, int64_t total /* = seg_off[Q] */,

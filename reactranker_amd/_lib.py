@@ -168,6 +168,10 @@ _SIGS = {
     "rr_segment_mean_bwd_f32": (i32, [c_f32p, i64, c_i32p, c_i32p, i64, i32, i32, f32, u64, c_f32p, i64, c_stream]),
     "rr_listmle_fwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, c_stream]),
     "rr_listmle_bwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, i64, c_stream]),
+    "rr_listmle_step_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, C.c_void_p, c_f32p, i64, c_stream]),
+    "rr_listnet_step_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, i64, c_f32p, c_f32p, C.c_void_p, c_f32p, i64, c_stream]),
+    "rr_evidential_ranking_step_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, C.c_void_p, c_f32p,
+                                             c_f32p, i64, c_stream]),
     "rr_listnet_fwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, i64, c_f32p, c_f32p, c_stream]),
     "rr_listnet_bwd_f32": (i32, [c_f32p, i64, c_f32p, c_i32p, i32, i32, i64, c_f32p, c_f32p, i64, c_stream]),
     "rr_evidential_ranking_fwd_f32": (i32, [c_f32p, c_f32p, i64, c_f32p, c_i32p, i32, i32, c_f32p, c_f32p, c_stream]),
@@ -216,7 +220,7 @@ class AdamTensor(C.Structure):
 RR_MAX_ADAM = 64
 RR_AMAX_LANES, RR_AMAX_STRIDE = 16, 32
 RR_AMAX_FLOATS = RR_AMAX_LANES * RR_AMAX_STRIDE
-ABI_VERSION = 7
+ABI_VERSION = 8
 (RR_SAVED_R_MSG, RR_SAVED_R_H, RR_SAVED_P_MSG, RR_SAVED_P_H, RR_SAVED_D_MSG, RR_SAVED_D_HID, RR_SAVED_VECS, RR_SAVED_FFN_H,
  RR_SAVED_R_MSG0_U, RR_SAVED_R_Z1_U) = range(10)
 

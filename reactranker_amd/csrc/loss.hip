@@ -97,6 +97,36 @@ __device__ inline void cumsum_exp_neg(const float* fd, float* out, int C, int la
   wave_sync();
 }
 
+// ---------------------------------------------------------------- fused loss + gradient launches ("step" entry points)
+// One launch writes the loss AND d loss / d score for an upstream gradient of one (what `loss.backward()` feeds a loss that
+// is the root of the graph): the reference's trainer step (train_listwise.py:287-288) then needs no second loss kernel, no
+// separate reduction launch and no host-created gradient.  After its partial is written every workgroup draws a ticket; the
+// one that draws the last sums all partials in reduce_scale_kernel's order - 256 strided accumulators, then its halving
+// tree; here on one wave, lane l playing threads l, l + 64, l + 128, l + 192 - so the loss has the bits of the two-kernel
+// path, and re-arms the counter (one zero-initialised device word the caller keeps) for the next launch.
+__device__ inline void finish_last(const float* partial, int n, float scale, float* out, unsigned int* counter, int lane) {
+  __threadfence();                                                   // release: this workgroup's partial
+  unsigned int ticket = 0u;
+  if (lane == 0) ticket = atomicAdd(counter, 1u);
+  ticket = __shfl(ticket, 0, RR_WAVE);
+  if (ticket != static_cast<unsigned int>(n) - 1u) return;
+  __threadfence();                                                   // acquire: every other workgroup's partial
+  float a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    float acc = 0.f;
+    for (int i = lane + 64 * u; i < n; i += 256) acc += partial[i];
+    a[u] = acc;
+  }
+  float r = (a[0] + a[2]) + (a[1] + a[3]);                           // tree steps o = 128 and o = 64
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o, RR_WAVE);  // red[t] += red[t + o] for t < o
+  if (lane == 0) {
+    out[0] = r * scale;
+    *counter = 0u;
+  }
+}
+
 // ---------------------------------------------------------------- ListMLE
 __global__ void __launch_bounds__(RR_WAVE) listmle_fwd_kernel(const float* __restrict__ score, int64_t sstride,
                                                               const float* __restrict__ targets,
@@ -151,6 +181,43 @@ __global__ void __launch_bounds__(RR_WAVE) listmle_bwd_kernel(const float* __res
   }
 }
 
+// forward + backward (upstream gradient one) of a list in one pass over its staged copy; same operations in the same order
+// as the two kernels above, so partial[q] and dscore have their bits
+__global__ void __launch_bounds__(RR_WAVE) listmle_step_kernel(const float* __restrict__ score, int64_t sstride,
+                                                               const float* __restrict__ targets,
+                                                               const int32_t* __restrict__ seg_off, int L, int Q,
+                                                               float* __restrict__ partial, float* __restrict__ dscore,
+                                                               int64_t dstride, float scale, float* __restrict__ loss,
+                                                               unsigned int* __restrict__ counter) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const int off = seg_off[q], C = seg_off[q + 1] - off;
+  if (C <= 0) {
+    if (lane == 0) partial[q] = 0.f;
+  } else {
+    ListView v = carve(sm, L);
+    for (int i = lane; i < C; i += RR_WAVE) {
+      v.s[i] = score[static_cast<int64_t>(off + i) * sstride];
+      v.t[i] = targets[off + i];
+    }
+    wave_sync();
+    rank_sort(v, C, lane);
+    const float m = list_max(v.ss, C, lane);
+    logcumsumexp_rev(v.ss, v.aux, C, lane, m);
+    float acc = 0.f;
+    for (int i = lane; i < C; i += RR_WAVE) acc += v.aux[i] - v.ss[i];
+    acc = rr_wave_sum(acc);
+    if (lane == 0) partial[q] = acc / static_cast<float>(C);
+    cumsum_exp_neg(v.aux, v.t, C, lane);
+    const float g = 1.0f / (static_cast<float>(C) * static_cast<float>(Q));
+    for (int j = lane; j < C; j += RR_WAVE) {
+      const float d = g * (expf(v.ss[j]) * v.t[j]) - g;
+      dscore[static_cast<int64_t>(off + v.perm[j]) * dstride] = d;
+    }
+  }
+  finish_last(partial, Q, scale, loss, counter, lane);
+}
+
 // ---------------------------------------------------------------- softmax helpers
 __device__ inline void softmax_stats(const float* a, int C, int lane, float* mx, float* sum) {
   const float m = list_max(a, C, lane);
@@ -166,12 +233,16 @@ __global__ void __launch_bounds__(RR_WAVE) listnet_kernel(const float* __restric
                                                           const int32_t* __restrict__ seg_off, int L, int bwd,
                                                           float* __restrict__ partial, const float* __restrict__ gloss,
                                                           float inv_total, float* __restrict__ dscore,
-                                                          int64_t dstride) {
+                                                          int64_t dstride, float* __restrict__ loss = nullptr,
+                                                          unsigned int* __restrict__ counter = nullptr) {
+  // bwd: 0 = forward (partial), 1 = backward (dscore), 2 = both in one pass + the last-arriver reduction (step entry point:
+  // gloss == nullptr means an upstream gradient of one)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int q = blockIdx.x, lane = threadIdx.x;
   const int off = seg_off[q], C = seg_off[q + 1] - off;
   if (C <= 0) {
-    if (!bwd && lane == 0) partial[q] = 0.f;
+    if (bwd != 1 && lane == 0) partial[q] = 0.f;
+    if (bwd == 2) finish_last(partial, gridDim.x, inv_total, loss, counter, lane);
     return;
   }
   float* s = sm;
@@ -184,7 +255,7 @@ __global__ void __launch_bounds__(RR_WAVE) listnet_kernel(const float* __restric
   float ms, zs, mt, zt;
   softmax_stats(s, C, lane, &ms, &zs);
   softmax_stats(t, C, lane, &mt, &zt);
-  if (!bwd) {
+  if (bwd != 1) {
     float acc = 0.f;
     for (int i = lane; i < C; i += RR_WAVE) {
       const float pred = logf(expf(s[i] - ms) / zs);                // torch.log(F.softmax(item)), loss.py:339
@@ -193,17 +264,19 @@ __global__ void __launch_bounds__(RR_WAVE) listnet_kernel(const float* __restric
     }
     acc = rr_wave_sum(acc);
     if (lane == 0) partial[q] = acc;
-  } else {
+  }
+  if (bwd != 0) {
     float tsum = 0.f;
     for (int i = lane; i < C; i += RR_WAVE) tsum += expf(t[i] - mt) / zt;
     tsum = rr_wave_sum(tsum);
-    const float g = gloss[0] * inv_total;
+    const float g = (gloss ? gloss[0] : 1.0f) * inv_total;
     for (int i = lane; i < C; i += RR_WAVE) {
       const float p = expf(s[i] - ms) / zs;
       const float targ = expf(t[i] - mt) / zt;
       dscore[static_cast<int64_t>(off + i) * dstride] = g * (p * tsum - targ);
     }
   }
+  if (bwd == 2) finish_last(partial, gridDim.x, inv_total, loss, counter, lane);
 }
 
 // ---------------------------------------------------------------- evidential UC-Listwise
@@ -212,12 +285,16 @@ __global__ void __launch_bounds__(RR_WAVE) evidential_kernel(const float* __rest
                                                              const int32_t* __restrict__ seg_off, int L, int Q, int bwd,
                                                              float* __restrict__ partial,
                                                              const float* __restrict__ gloss, float* __restrict__ dmu,
-                                                             float* __restrict__ dvar, int64_t dstride) {
+                                                             float* __restrict__ dvar, int64_t dstride,
+                                                             float* __restrict__ loss = nullptr,
+                                                             unsigned int* __restrict__ counter = nullptr) {
+  // bwd: 0 = forward, 1 = backward, 2 = both + the last-arriver reduction (see listnet_kernel)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int q = blockIdx.x, lane = threadIdx.x;
   const int off = seg_off[q], C = seg_off[q + 1] - off;
   if (C <= 0) {
-    if (!bwd && lane == 0) partial[q] = 0.f;
+    if (bwd != 1 && lane == 0) partial[q] = 0.f;
+    if (bwd == 2) finish_last(partial, gridDim.x, 1.0f / static_cast<float>(Q), loss, counter, lane);
     return;
   }
   float* s = sm;
@@ -233,7 +310,7 @@ __global__ void __launch_bounds__(RR_WAVE) evidential_kernel(const float* __rest
   softmax_stats(s, C, lane, &ms, &zs);
   softmax_stats(t, C, lane, &mt, &zt);
   const float two_pi = 2.0f * 3.141592653f;                         // loss.py:543 (truncated pi)
-  if (!bwd) {
+  if (bwd != 1) {
     float acc = 0.f;
     for (int i = lane; i < C; i += RR_WAVE) {
       const float lp = logf(expf(s[i] - ms) / zs);
@@ -245,7 +322,8 @@ __global__ void __launch_bounds__(RR_WAVE) evidential_kernel(const float* __rest
     }
     acc = rr_wave_sum(acc);
     if (lane == 0) partial[q] = acc / static_cast<float>(C);
-  } else {
+  }
+  if (bwd != 0) {
     float csum = 0.f;
     for (int i = lane; i < C; i += RR_WAVE) {
       const float lp = logf(expf(s[i] - ms) / zs);
@@ -253,7 +331,7 @@ __global__ void __launch_bounds__(RR_WAVE) evidential_kernel(const float* __rest
       csum += -(lt - lp) / vv[i];
     }
     csum = rr_wave_sum(csum);
-    const float g = gloss[0] / (static_cast<float>(C) * static_cast<float>(Q));
+    const float g = (gloss ? gloss[0] : 1.0f) / (static_cast<float>(C) * static_cast<float>(Q));
     for (int i = lane; i < C; i += RR_WAVE) {
       const float p = expf(s[i] - ms) / zs;
       const float lp = logf(p);
@@ -266,6 +344,7 @@ __global__ void __launch_bounds__(RR_WAVE) evidential_kernel(const float* __rest
       dvar[static_cast<int64_t>(off + i) * dstride] = g * (-0.5f * d * d / (vv[i] * vv[i]) + 0.5f / vv[i]);
     }
   }
+  if (bwd == 2) finish_last(partial, gridDim.x, 1.0f / static_cast<float>(Q), loss, counter, lane);
 }
 
 // ---------------------------------------------------------------- RankNet
@@ -642,6 +721,25 @@ int rr_listmle_bwd_f32(const float* score, int64_t score_stride, const float* ta
   return rr_launch_status();
 }
 
+int rr_listmle_step_f32(const float* score, int64_t score_stride, const float* targets, const int32_t* seg_off, int Q, int max_len,
+                        float* loss, float* partial, unsigned int* counter, float* dscore, int64_t dscore_stride,
+                        rr_stream_t stream) {
+  RR_CHECK_ARG(list_args_ok(score, targets, seg_off, Q, max_len) && loss && partial && counter && dscore && score_stride >= 1 &&
+               dscore_stride >= 1);
+  if (max_len > kMaxLen) return RR_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (Q == 0) {                                          // nothing to rank: the loss is the empty mean the forward entry point writes
+    reduce_scale_kernel<<<1, 256, 0, s>>>(partial, 0, 1, 0.f, loss);
+    return rr_launch_status();
+  }
+  const int L = max_len > 0 ? max_len : 1;
+  const size_t lds = 5u * L * sizeof(float);
+  if (set_lds(listmle_step_kernel, lds) != RR_OK) return RR_ERR_LAUNCH;
+  listmle_step_kernel<<<Q, RR_WAVE, lds, s>>>(score, score_stride, targets, seg_off, L, Q, partial, dscore, dscore_stride,
+                                              1.0f / static_cast<float>(Q), loss, counter);
+  return rr_launch_status();
+}
+
 int rr_listnet_fwd_f32(const float* score, int64_t score_stride, const float* targets, const int32_t* seg_off, int Q,
                        int max_len, int64_t total, float* loss, float* partial, rr_stream_t stream) {
   RR_CHECK_ARG(list_args_ok(score, targets, seg_off, Q, max_len) && loss && partial && score_stride >= 1 && total >= 0);
@@ -675,6 +773,25 @@ int rr_listnet_bwd_f32(const float* score, int64_t score_stride, const float* ta
   return rr_launch_status();
 }
 
+int rr_listnet_step_f32(const float* score, int64_t score_stride, const float* targets, const int32_t* seg_off, int Q, int max_len,
+                        int64_t total, float* loss, float* partial, unsigned int* counter, float* dscore, int64_t dscore_stride,
+                        rr_stream_t stream) {
+  RR_CHECK_ARG(list_args_ok(score, targets, seg_off, Q, max_len) && loss && partial && counter && dscore && score_stride >= 1 &&
+               dscore_stride >= 1 && total >= 0);
+  if (max_len > kMaxLen) return RR_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (Q == 0 || total == 0) {
+    reduce_scale_kernel<<<1, 256, 0, s>>>(partial, 0, 1, 0.f, loss);
+    return rr_launch_status();
+  }
+  const int L = max_len > 0 ? max_len : 1;
+  const size_t lds = 2u * L * sizeof(float);
+  if (set_lds(listnet_kernel, lds) != RR_OK) return RR_ERR_LAUNCH;
+  listnet_kernel<<<Q, RR_WAVE, lds, s>>>(score, score_stride, targets, seg_off, L, 2, partial, nullptr,
+                                         1.0f / static_cast<float>(total), dscore, dscore_stride, loss, counter);
+  return rr_launch_status();
+}
+
 int rr_evidential_ranking_fwd_f32(const float* mu, const float* var, int64_t stride, const float* targets,
                                   const int32_t* seg_off, int Q, int max_len, float* loss, float* partial,
                                   rr_stream_t stream) {
@@ -705,6 +822,25 @@ int rr_evidential_ranking_bwd_f32(const float* mu, const float* var, int64_t str
   if (set_lds(evidential_kernel, lds) != RR_OK) return RR_ERR_LAUNCH;
   evidential_kernel<<<Q, RR_WAVE, lds, s>>>(mu, var, stride, targets, seg_off, L, Q, 1, nullptr, gloss, dmu, dvar,
                                             dstride);
+  return rr_launch_status();
+}
+
+int rr_evidential_ranking_step_f32(const float* mu, const float* var, int64_t stride, const float* targets, const int32_t* seg_off,
+                                   int Q, int max_len, float* loss, float* partial, unsigned int* counter, float* dmu, float* dvar,
+                                   int64_t dstride, rr_stream_t stream) {
+  RR_CHECK_ARG(list_args_ok(mu, targets, seg_off, Q, max_len) && var && loss && partial && counter && dmu && dvar && stride >= 1 &&
+               dstride >= 1);
+  if (max_len > kMaxLen) return RR_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (Q == 0) {
+    reduce_scale_kernel<<<1, 256, 0, s>>>(partial, 0, 1, 0.f, loss);
+    return rr_launch_status();
+  }
+  const int L = max_len > 0 ? max_len : 1;
+  const size_t lds = 3u * L * sizeof(float);
+  if (set_lds(evidential_kernel, lds) != RR_OK) return RR_ERR_LAUNCH;
+  evidential_kernel<<<Q, RR_WAVE, lds, s>>>(mu, var, stride, targets, seg_off, L, Q, 2, partial, nullptr, dmu, dvar, dstride, loss,
+                                            counter);
   return rr_launch_status();
 }
 

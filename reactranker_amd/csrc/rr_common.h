@@ -10,7 +10,7 @@
 
 #include "../../include/reactranker_hip.h"
 
-#define RR_ABI_VERSION 7
+#define RR_ABI_VERSION 8
 #define RR_WAVE 64
 #define RR_NUM_CU 256   // MI355X: 8 XCDs x 32 CUs
 

@@ -57,19 +57,81 @@ def _f1(dev):
     return torch.empty(1, dtype=torch.float32, device=dev)
 
 
+class FusedStep:
+    """Loss and d loss / d score in ONE launch (rr_listmle_step_f32 and its ListNet / evidential twins, csrc/loss.hip).
+
+    The reference's trainer step is `loss = loss_func(score, ...); loss.backward()` (train/train_listwise.py:287-288): the loss
+    is the root of the graph and its upstream gradient is the constant one.  When the score requires a gradient the forward
+    therefore also writes d loss / d score for that case - same operations in the same order as the backward kernel with an
+    upstream gradient of 1.0f, the bits are the same - and `reactranker_amd.loss.backward(loss)` starts the backward with the
+    library's cached constant-one tensor: the loss's backward then recognises it (by address) and hands out the gradient
+    that already exists.  What a step no longer launches: the separate reduction of the per-query partials, autograd's
+    ones_like(loss) fill, a `.sum()` over one element, the loss's backward kernel.  Any other upstream gradient (a plain
+    `loss.backward()`, a scaled loss) takes the backward kernel as before - nothing depends on the fast path being hit.
+    hits counts the backward calls it served (tests)."""
+    enabled = True
+    hits = 0
+    _unit = {}
+    _counter = {}
+
+
+def _unit_like(t: torch.Tensor) -> torch.Tensor:
+    key = (str(t.device), tuple(t.shape))
+    u = FusedStep._unit.get(key)
+    if u is None:
+        u = FusedStep._unit[key] = torch.ones(tuple(t.shape), dtype=torch.float32, device=t.device)
+    return u
+
+
+def _is_unit(g: torch.Tensor) -> bool:
+    u = FusedStep._unit.get((str(g.device), tuple(g.shape)))
+    return u is not None and g.dtype == torch.float32 and g.data_ptr() == u.data_ptr()
+
+
+def _counter(dev) -> torch.Tensor:
+    """the zero-initialised ticket word of the step kernels: one per (device, stream) - launches of one stream are ordered,
+    and every launch leaves it at zero"""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    c = FusedStep._counter.get(key)
+    if c is None:
+        c = FusedStep._counter[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return c
+
+
+def backward(loss: torch.Tensor) -> None:
+    """`loss.backward()` for a loss that is the root of the graph (reference train/train_listwise.py:288), started with the
+    library's constant-one gradient instead of a freshly filled one: a loss of this module then returns the gradient its
+    forward launch already wrote (FusedStep).  Works for any other one-element float32 loss as well (plain autograd)."""
+    if loss.numel() == 1 and loss.dtype == torch.float32 and loss.is_cuda:
+        loss.backward(gradient=_unit_like(loss))
+    else:
+        loss.backward()
+
+
 class _ListMLEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, score, targets, seg, Q, max_len):
         s = _vec(score.detach())
         loss, part = _f1(s.device), torch.empty(max(Q, 1), dtype=torch.float32, device=s.device)
-        check(lib().rr_listmle_fwd_f32(ptr(s), s.stride(0), ptr(targets), ptr(seg), Q, max_len, ptr(loss), ptr(part),
-                                       stream()), "rr_listmle_fwd_f32")
+        ctx.ds_unit = None
+        if FusedStep.enabled and ctx.needs_input_grad[0]:
+            ds = torch.empty(s.shape[0], dtype=torch.float32, device=s.device)
+            check(lib().rr_listmle_step_f32(ptr(s), s.stride(0), ptr(targets), ptr(seg), Q, max_len, ptr(loss), ptr(part),
+                                            ptr(_counter(s.device)), ptr(ds), 1, stream()), "rr_listmle_step_f32")
+            ctx.ds_unit = ds
+        else:
+            check(lib().rr_listmle_fwd_f32(ptr(s), s.stride(0), ptr(targets), ptr(seg), Q, max_len, ptr(loss), ptr(part),
+                                           stream()), "rr_listmle_fwd_f32")
         ctx.save_for_backward(s, targets, seg)
         ctx.meta = (Q, max_len)
         return loss
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.ds_unit is not None and _is_unit(g):      # the gradient the forward launch already wrote (handed out once)
+            ds, ctx.ds_unit = ctx.ds_unit, None
+            FusedStep.hits += 1
+            return ds, None, None, None, None
         s, targets, seg = ctx.saved_tensors
         Q, max_len = ctx.meta
         g = g.reshape(-1).contiguous().float()
@@ -84,14 +146,25 @@ class _ListNetFn(torch.autograd.Function):
     def forward(ctx, score, targets, seg, Q, max_len, total):
         s = _vec(score.detach())
         loss, part = _f1(s.device), torch.empty(max(Q, 1), dtype=torch.float32, device=s.device)
-        check(lib().rr_listnet_fwd_f32(ptr(s), s.stride(0), ptr(targets), ptr(seg), Q, max_len, total, ptr(loss),
-                                       ptr(part), stream()), "rr_listnet_fwd_f32")
+        ctx.ds_unit = None
+        if FusedStep.enabled and ctx.needs_input_grad[0]:
+            ds = torch.empty(s.shape[0], dtype=torch.float32, device=s.device)
+            check(lib().rr_listnet_step_f32(ptr(s), s.stride(0), ptr(targets), ptr(seg), Q, max_len, total, ptr(loss), ptr(part),
+                                            ptr(_counter(s.device)), ptr(ds), 1, stream()), "rr_listnet_step_f32")
+            ctx.ds_unit = ds
+        else:
+            check(lib().rr_listnet_fwd_f32(ptr(s), s.stride(0), ptr(targets), ptr(seg), Q, max_len, total, ptr(loss),
+                                           ptr(part), stream()), "rr_listnet_fwd_f32")
         ctx.save_for_backward(s, targets, seg)
         ctx.meta = (Q, max_len, total)
         return loss.reshape(())                         # torch.mean -> 0-d (reference loss.py:347)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.ds_unit is not None and _is_unit(g):
+            ds, ctx.ds_unit = ctx.ds_unit, None
+            FusedStep.hits += 1
+            return ds, None, None, None, None, None
         s, targets, seg = ctx.saved_tensors
         Q, max_len, total = ctx.meta
         g = g.reshape(-1).contiguous().float()
@@ -109,14 +182,26 @@ class _EvidentialFn(torch.autograd.Function):
             p = p.float().reshape(-1, 2).contiguous()
         loss, part = _f1(p.device), torch.empty(max(Q, 1), dtype=torch.float32, device=p.device)
         mu, var = p[:, 0], p[:, 1]
-        check(lib().rr_evidential_ranking_fwd_f32(ptr(mu), ptr(var), p.stride(0), ptr(targets), ptr(seg), Q, max_len,
-                                                  ptr(loss), ptr(part), stream()), "rr_evidential_ranking_fwd_f32")
+        ctx.ds_unit = None
+        if FusedStep.enabled and ctx.needs_input_grad[0]:
+            d = torch.empty(p.shape[0], 2, dtype=torch.float32, device=p.device)
+            check(lib().rr_evidential_ranking_step_f32(ptr(mu), ptr(var), p.stride(0), ptr(targets), ptr(seg), Q, max_len,
+                                                       ptr(loss), ptr(part), ptr(_counter(p.device)), ptr(d[:, 0]), ptr(d[:, 1]), 2,
+                                                       stream()), "rr_evidential_ranking_step_f32")
+            ctx.ds_unit = d
+        else:
+            check(lib().rr_evidential_ranking_fwd_f32(ptr(mu), ptr(var), p.stride(0), ptr(targets), ptr(seg), Q, max_len,
+                                                      ptr(loss), ptr(part), stream()), "rr_evidential_ranking_fwd_f32")
         ctx.save_for_backward(p, targets, seg)
         ctx.meta = (Q, max_len)
         return loss
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.ds_unit is not None and _is_unit(g):
+            d, ctx.ds_unit = ctx.ds_unit, None
+            FusedStep.hits += 1
+            return d, None, None, None, None
         p, targets, seg = ctx.saved_tensors
         Q, max_len = ctx.meta
         g = g.reshape(-1).contiguous().float()

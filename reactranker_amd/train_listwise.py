@@ -170,7 +170,7 @@ def _train(model, scheduler, train_batches, val_batches, path_checkpoints, optim
             if len(b["scope"]) > 0:
                 output = model(b["r"], b["p"], gpu=gpu, add_features=b.get("add"))
                 loss = batch_loss(task_type, output, b["scope"], b["targets"], gpu, epoch, epochs, max_coeff)
-                loss.sum().backward()
+                RL.backward(loss)                       # loss.backward() (:288) seeded with the library's constant one (loss.FusedStep)
             else:                                       # an empty shard: this rank adds nothing to the step
                 loss = torch.zeros(1, device=dev)
             if ex.on:

@@ -12,7 +12,7 @@ from typing import Iterable
 
 import torch
 
-from .loss import ranknet_lambda, ranknet_loss
+from .loss import backward as loss_backward, ranknet_lambda, ranknet_loss
 
 
 def factorized_training_loop(epoch: int, model, optimizer, scheduler, batches: Iterable, sigma: float = 1.0,
@@ -50,7 +50,7 @@ def factorized_training_loop(epoch: int, model, optimizer, scheduler, batches: I
                                        b["targets"], sigma, gpu)
             loss = loss_sum / pairs
             if training_algo == "sum_session":
-                loss.sum().backward()
+                loss_backward(loss)
             else:
                 back = ranknet_lambda(y_pred, b["scope"], b["targets"], sigma, gpu)
                 y_pred.backward(back / pairs)

@@ -278,3 +278,79 @@ def test_ranking_metrics_at_the_longest_supported_list():
     assert np.allclose(stats[:, 10].cpu().numpy(), rows[:, 1], rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         RE.ranking_stats(torch.zeros(8193, device="cuda"), [8193], np.zeros(8193, np.float32), 0)
+
+
+@pytest.mark.parametrize("scope", [[64] * 64, [1, 2, 3, 32, 64, 65, 129, 300], [5, 0, 7, 0], [3], [40] * 300])
+def test_fused_loss_step_has_the_bits_of_the_two_kernel_path(scope, parity_log):
+    """rr_listmle_step_f32 / rr_listnet_step_f32 / rr_evidential_ranking_step_f32 (ABI revision 8): loss AND d loss / d score in
+    one launch, the per-query partials summed by the last workgroup in the reduction kernel's order.  Loss and gradient must be
+    torch.equal to the forward kernel + reduction + backward kernel sequence; `RL.backward(loss)` must be served by the
+    gradient the forward already wrote (FusedStep.hits); a plain loss.backward() and a scaled loss take the backward kernel
+    and give the same numbers; the ticket word re-arms itself (three launches in a row)."""
+    rng = np.random.default_rng(11)
+    m = sum(scope)
+    score = torch.tensor((rng.standard_normal(m) * 2).astype(np.float32)).cuda()
+    var = torch.tensor((np.log1p(np.exp(rng.standard_normal(m))) + 1e-3).astype(np.float32)).cuda()
+    targets = torch.tensor(rng.standard_normal(m).astype(np.float32))
+
+    def run(kind, fused, how):
+        RL.FusedStep.enabled = fused
+        try:
+            if kind == "evid":
+                x = torch.stack([score, var], 1).clone().requires_grad_(True)
+                l = RL.evidential_ranking()(x, scope, targets, None, None, None, 0)
+            else:
+                x = score.clone().requires_grad_(True)
+                l = (RL.MLEloss() if kind == "mle" else RL.ListnetLoss())(x, scope, targets, 0)
+            if how == "unit":
+                RL.backward(l)
+            elif how == "plain":
+                l.sum().backward()
+            else:
+                (l * 0.37).sum().backward()
+            return l.detach().clone(), x.grad.clone()
+        finally:
+            RL.FusedStep.enabled = True
+
+    for kind in ("mle", "listnet", "evid"):
+        for how in ("unit", "plain", "scaled"):
+            l0, g0 = run(kind, False, how)
+            for rep in range(3):
+                h0 = RL.FusedStep.hits
+                l1, g1 = run(kind, True, how)
+                assert torch.equal(l0, l1), (kind, how, float(l0.sum()), float(l1.sum()))
+                assert torch.equal(g0, g1), (kind, how, float((g0 - g1).abs().max()))
+                assert RL.FusedStep.hits - h0 == (1 if how == "unit" else 0), (kind, how)
+    parity_log(f"scope of {len(scope)} lists / {m} candidates: fused step == two-kernel path bit for bit (mle, listnet, evidential; "
+               "unit, plain and scaled upstream gradients; 3 launches each)")
+
+
+def test_fused_loss_step_inside_a_training_step_reaches_the_model_gradients():
+    """the gradient handed out by the fused step drives the model's explicit backward: parameter gradients equal those of the
+    two-kernel path bit for bit"""
+    from oracle import ref_cpu as O
+    from reactranker_amd import featurization, synth
+    from tests.test_gpu_model import make_model
+    cfg = dict(hidden_size=32, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1, ffn_last_layer="with_softplus",
+               task_type=None, add_features_dim=1)
+    w = synth.seeded_weights(O.model_shapes(32, 3, 3, 3, 1, 1, True), 5)
+    model = make_model(cfg, w, dropout=0.1).train()
+    qb = synth.make_queries(17, 4, [7, 3, 9, 5], atoms_lo=5, atoms_hi=14)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    res = []
+    for fused in (False, True):
+        RL.FusedStep.enabled = fused
+        try:
+            model.zero_grad()
+            model.dropout_seed = 77
+            out = model(rb, pb, gpu=0, add_features=qb.add_features)
+            l = RL.MLEloss()(out, qb.scope, torch.tensor(qb.targets), 0)
+            h0 = RL.FusedStep.hits
+            RL.backward(l)
+            assert RL.FusedStep.hits - h0 == (1 if fused else 0)
+            res.append((l.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+        finally:
+            RL.FusedStep.enabled = True
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
