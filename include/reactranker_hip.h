@@ -541,6 +541,40 @@ int rr_derive_tables(const int32_t* a2b, const int32_t* b2a, const int32_t* b2re
                      int32_t* a2a, int32_t* a2b_rev_t, int32_t* b2t, int32_t* a2a_t,
                      float* npad, int32_t* atom2mol);
 
+/* ------------------------------------------------------------------ FFN head as one launch (ABI revision 8) --- */
+/* The FFN head (models/base_model.py:32-60) and its input-gradient chain: up to RR_MAX_FFN dependent small GEMMs - one row per
+ * molecule - in ONE launch; a workgroup owns 16 rows and walks every stage, the activations stay in LDS between stages
+ * (csrc/ffn.hip).  Stage s computes  y = x_s W_s^T (+ bias) [ReLU] [dropout]  on the f32 MFMA with W_s in the packed layout of
+ * rr_pack_weights_f32 (split = 0: [n_out][r16(n_in)] zero-padded), writes y to `out` (may be NULL except for the last stage)
+ * and hands  x_{s+1} = post_mask ? (post_mask > 0 ? y * mask_scale : 0) : y  to the next stage, which reads its first n_in
+ * columns.  rowdot = 1 (last stage only, n_out <= 8, n_in % 4 == 0, plain row-major weight rows of pitch ldw): the 16-lane dot
+ * product of the scorer's last Linear.  Results are bit-identical to the same layers issued one by one through
+ * rr_linear_f32 (M <= 8192 geometry or not).  Forward chain: stages = the Linear layers, ReLU + dropout on all but the last
+ * (rowdot); backward chain: stages = the layers in reverse with their transposed packs, post_mask = the forward layer's
+ * output below.  Returns RR_ERR_UNSUPPORTED for shapes it does not take (unaligned rows, n_out % 4 != 0, widths > 1024):
+ * issue the layers one by one then. */
+#ifndef RR_MAX_FFN
+#define RR_MAX_FFN 8
+#endif
+typedef struct rr_ffn_stage {
+  const float* w;  int64_t ldw;       /* packed weight [n_out][ldw], ldw = r16(n_in) (rowdot: any row-major [n_out][ldw >= n_in]) */
+  const float* bias;                  /* [n_out] or NULL */
+  int n_out, n_in;
+  int relu, dropout, rowdot;
+  uint64_t drop_seed;                 /* dropout stream of this stage (rate: rr_ffn_chain_args.drop_p; element m * n_out + n) */
+  float* out;  int64_t ld_out;        /* y [M, ld_out] or NULL */
+  const float* post_mask;  int64_t ld_mask;   /* [M, ld_mask] or NULL */
+} rr_ffn_stage;
+typedef struct rr_ffn_chain_args {
+  int64_t M;
+  int n_stages;
+  const float* x;  int64_t ldx;       /* input of stage 0: [M, ldx], its first stage[0].n_in columns */
+  float drop_p, mask_scale;
+  rr_ffn_stage stage[RR_MAX_FFN];
+} rr_ffn_chain_args;
+size_t rr_abi_ffn_chain_size(void);
+int rr_ffn_chain_f32(const rr_ffn_chain_args* args, rr_stream_t stream);
+
 /* ------------------------------------------------------------------ whole-model step plans --- */
 /* ReactionModel.forward (models/base_model.py:150-171: encoder on reactants and products, p_h - r_h, diff encoder,
  * readout, FFN + head) and its explicit backward as ONE call each: the host-side orchestration of the per-op entry
@@ -551,7 +585,9 @@ int rr_derive_tables(const int32_t* a2b, const int32_t* b2a, const int32_t* b2re
  * (what the packer produces); other shapes use the per-op entry points.  Device pointers unless noted.
  * A data-parallel step is forward, loss kernel, backward, then ONE all-reduce of the gradient buffers handed to
  * rr_reaction_backward (rr_allreduce_f32 below, or the host's own collective - the Python mirror uses torch.distributed). */
+#ifndef RR_MAX_FFN
 #define RR_MAX_FFN 8
+#endif
 
 typedef struct rr_graph {             /* a packed batch resident in HBM (arrays of rr_pack_graphs / rr_derive_*) */
   int64_t nA, nB, M;
@@ -589,10 +625,12 @@ enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2,
                                         input-gradient GEMMs, in the same launch as the forward's packs, so the backward
                                         starts with its first GEMM instead of a pack.  Layout-changing like RR_PLAN_F32_GEMM:
                                         pass the same flags to both calls (ABI revision 6). */
-       RR_PLAN_F16X2_GEMM = 32 };    /* encoder GEMMs and weight gradients on two f16 terms per operand (w_packed = 3: half the
+       RR_PLAN_F16X2_GEMM = 32,      /* encoder GEMMs and weight gradients on two f16 terms per operand (w_packed = 3: half the
                                         matrix instructions of the three-bf16-term path, 22 significant bits per operand); the
                                         plan finds every operand's largest magnitude itself (rr_amax_f32, one slot per tensor
                                         in the workspace).  Ignored with RR_PLAN_F32_GEMM; layout-changing (ABI revision 7). */
+       RR_PLAN_NO_FFN_CHAIN = 64 };  /* the FFN head's layers as separate launches instead of rr_ffn_chain_f32 (same results
+                                        bit for bit, same workspace layout: an A/B knob; ABI revision 8) */
 
 typedef struct rr_step {
   rr_graph p, r, u;

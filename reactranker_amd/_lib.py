@@ -82,6 +82,22 @@ RR_MAX_FFN = 8
 RR_G_FFN0 = 6
 RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
 RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM, RR_PLAN_AUX_BACKWARD, RR_PLAN_TRAIN, RR_PLAN_F16X2_GEMM = 1, 2, 4, 8, 16, 32
+RR_PLAN_NO_FFN_CHAIN = 64
+
+
+class FfnStage(C.Structure):
+    _fields_ = [
+        ("w", c_f32p), ("ldw", i64), ("bias", c_f32p), ("n_out", i32), ("n_in", i32),
+        ("relu", i32), ("dropout", i32), ("rowdot", i32), ("drop_seed", u64),
+        ("out", c_f32p), ("ld_out", i64), ("post_mask", c_f32p), ("ld_mask", i64),
+    ]
+
+
+class FfnChainArgs(C.Structure):
+    _fields_ = [
+        ("M", i64), ("n_stages", i32), ("x", c_f32p), ("ldx", i64), ("drop_p", f32), ("mask_scale", f32),
+        ("stage", FfnStage * RR_MAX_FFN),
+    ]
 
 
 class Graph(C.Structure):
@@ -195,6 +211,8 @@ _SIGS = {
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
     "rr_abi_plan_struct_sizes": (None, [C.POINTER(C.c_size_t)] * 4),
+    "rr_abi_ffn_chain_size": (C.c_size_t, []),
+    "rr_ffn_chain_f32": (i32, [C.POINTER(FfnChainArgs), c_stream]),
     "rr_reaction_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(Step)]),
     "rr_reaction_forward": (i32, [C.POINTER(Model), C.POINTER(Step), i32, c_stream]),
     "rr_reaction_backward": (i32, [C.POINTER(Model), C.POINTER(Step), c_f32p, C.POINTER(Grads), i32, c_stream]),
@@ -251,6 +269,8 @@ def lib():
         l.rr_abi_plan_struct_sizes(*[C.byref(x) for x in sz])
         if [x.value for x in sz] != [C.sizeof(Graph), C.sizeof(Model), C.sizeof(Step), C.sizeof(Grads)]:
             raise RuntimeError("reactranker_amd: ctypes plan struct layout differs from the compiled header")
+        if l.rr_abi_ffn_chain_size() != C.sizeof(FfnChainArgs):
+            raise RuntimeError("reactranker_amd: ctypes rr_ffn_chain_args layout differs from the compiled header")
         _lib = l
     return _lib
 

@@ -123,6 +123,7 @@ struct Ctx {
   Streams s;
   bool use_side, use_aux, aux_bwd;
   bool train;                         // RR_PLAN_TRAIN: the forward packs the backward's transposed weights too
+  bool ffn_chain;                     // the FFN head and its input-gradient chain as one launch each (rr_ffn_chain_f32)
   hipStream_t cur;                    // stream of the backward chain being enqueued (main, or aux for the reactant pass)
   bool split;                         // encoder GEMMs on the bf16 matrix core (three exact bf16 terms per f32 operand)
   rr_pack_desc pq[RR_MAX_PACK];       // weight packs waiting for flush_packs()
@@ -484,27 +485,59 @@ void mpndiff_forward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW
   RR_TRY(c, rr_segment_mean_fwd_f32(S.hid, H, g.a_scope, g.M, H, feat, F, p, out_seed, S.vecs, S.ld_vecs, st));   // :224-238
 }
 
+// FFN.forward after its input dropout (models/base_model.py:32-60).  The whole head is ONE launch where rr_ffn_chain_f32 takes the
+// shape (csrc/ffn.hip: bit-identical to the layers issued one by one); otherwise - RR_PLAN_NO_FFN_CHAIN, an odd width, the
+// MFMA form of the last layer asked for with RR_NO_ROWDOT - the per-layer launches below.  Same workspace layout either way.
 void ffn_forward(Ctx& c, const rr_model& m, const PackedW& pk, int64_t M, float p, uint64_t seed, const float* x, int64_t ldx,
                  float* out, FfnSaved& S, hipStream_t st) {
   S.hs[0] = const_cast<float*>(x);
   S.ld_hs[0] = ldx;
   for (int li = 0; li < m.n_ffn - 1; ++li) {
-    const rr_linear_w& L = m.ffn[li];
-    S.ld_hs[li + 1] = r4(L.out);
+    S.ld_hs[li + 1] = r4(m.ffn[li].out);
     S.hs[li + 1] = c.alloc(M, S.ld_hs[li + 1]);
-    rr_linear_args a = LA(M, L.out);
-    a.a1 = S.hs[li]; a.lda1 = S.ld_hs[li]; a.k1 = L.in;
-    set_w(a, pk.ffn[li]); a.bias = L.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 4000 + li);
-    a.c = S.hs[li + 1]; a.ldc = S.ld_hs[li + 1];
-    lin(c, a, st);
   }
   const rr_linear_w& L = m.ffn[m.n_ffn - 1];
   S.raw = m.head == 0 ? out : c.alloc(M, L.out);
-  rr_linear_args a = LA(M, L.out);
-  a.a1 = S.hs[m.n_ffn - 1]; a.lda1 = S.ld_hs[m.n_ffn - 1]; a.k1 = L.in;
-  set_w(a, pk.ffn[m.n_ffn - 1]); a.bias = L.b;
-  a.c = S.raw; a.ldc = L.out;
-  lin(c, a, st);
+  bool chained = false;
+  if (c.ffn_chain && m.n_ffn >= 2 && L.out <= 8 && L.in % 4 == 0 && pk.ffn[m.n_ffn - 1].mode == 1 && !getenv("RR_NO_ROWDOT") &&
+      c.launch && c.status == RR_OK) {
+    rr_ffn_chain_args a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.n_stages = m.n_ffn; a.x = x; a.ldx = ldx; a.drop_p = p; a.mask_scale = 1.0f;
+    bool ok = true;
+    for (int li = 0; li < m.n_ffn; ++li) {
+      rr_ffn_stage& g = a.stage[li];
+      const rr_linear_w& Ll = m.ffn[li];
+      ok = ok && pk.ffn[li].mode == 1;
+      g.w = pk.ffn[li].w; g.ldw = pk.ffn[li].ld; g.bias = Ll.b; g.n_out = Ll.out; g.n_in = Ll.in;
+      if (li < m.n_ffn - 1) {
+        g.relu = 1; g.dropout = 1; g.drop_seed = site_seed(seed, 4000 + li);
+        g.out = S.hs[li + 1]; g.ld_out = S.ld_hs[li + 1];
+      } else {
+        g.rowdot = 1; g.out = S.raw; g.ld_out = L.out;
+      }
+    }
+    if (ok) {
+      const int stc = rr_ffn_chain_f32(&a, st);
+      if (stc == RR_OK) chained = true;
+      else if (stc != RR_ERR_UNSUPPORTED) c.fail(stc);
+    }
+  }
+  if (!chained) {
+    for (int li = 0; li < m.n_ffn - 1; ++li) {
+      const rr_linear_w& Ll = m.ffn[li];
+      rr_linear_args a = LA(M, Ll.out);
+      a.a1 = S.hs[li]; a.lda1 = S.ld_hs[li]; a.k1 = Ll.in;
+      set_w(a, pk.ffn[li]); a.bias = Ll.b; a.act = RR_ACT_RELU; a.drop_p = p; a.drop_seed = site_seed(seed, 4000 + li);
+      a.c = S.hs[li + 1]; a.ldc = S.ld_hs[li + 1];
+      lin(c, a, st);
+    }
+    rr_linear_args a = LA(M, L.out);
+    a.a1 = S.hs[m.n_ffn - 1]; a.lda1 = S.ld_hs[m.n_ffn - 1]; a.k1 = L.in;
+    set_w(a, pk.ffn[m.n_ffn - 1]); a.bias = L.b;
+    a.c = S.raw; a.ldc = L.out;
+    lin(c, a, st);
+  }
   if (m.head != 0) RR_TRY(c, rr_head_fwd_f32(S.raw, M, L.out, m.head, out, st));
 }
 
@@ -846,36 +879,59 @@ float* ffn_backward(Ctx& c, const rr_model& m, int64_t M, float p, const FfnSave
     w.x1 = S.hs[nl - 1]; w.ldx1 = S.ld_hs[nl - 1]; w.k1 = L.in;
     wgrad(c, w);
   }
-  const int ncur = ffn_dx_rows(m, nl - 1);
-  float* dx = c.alloc(M, r4(ncur));
-  int64_t ld_dx = r4(ncur);
-  {
+  // the input gradients of every layer: dx[nl-1] = d W_last, dx[li] = (dx[li+1] * relu'/dropout pattern of hs[li+1]) W_li
+  float* dx[RR_MAX_FFN];
+  int64_t ldx[RR_MAX_FFN];
+  for (int li = nl - 1; li >= 0; --li) {
+    ldx[li] = r4(ffn_dx_rows(m, li));
+    dx[li] = c.alloc(M, ldx[li]);
+  }
+  // ONE launch for the whole chain where rr_ffn_chain_f32 takes the shape (see ffn_forward); the weight gradients of the hidden
+  // layers, which read the chain's intermediate dx, are issued after it (each writes its own buffers: the order is free)
+  bool chained = false;
+  if (c.ffn_chain && nl >= 2 && c.launch && c.status == RR_OK) {
+    rr_ffn_chain_args a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.n_stages = nl; a.x = d; a.ldx = L.out; a.drop_p = 0.f; a.mask_scale = ks;
+    bool ok = true;
+    for (int j = 0; j < nl; ++j) {
+      const int li = nl - 1 - j;
+      rr_ffn_stage& g = a.stage[j];
+      ok = ok && T.ffn[li].mode == 1;
+      g.w = T.ffn[li].w; g.ldw = T.ffn[li].ld; g.n_out = ffn_dx_rows(m, li); g.n_in = m.ffn[li].out;
+      g.out = dx[li]; g.ld_out = ldx[li];
+      if (li > 0) { g.post_mask = S.hs[li]; g.ld_mask = S.ld_hs[li]; }
+    }
+    if (ok) {
+      const int stc = rr_ffn_chain_f32(&a, st);
+      if (stc == RR_OK) chained = true;
+      else if (stc != RR_ERR_UNSUPPORTED) c.fail(stc);
+    }
+  }
+  if (!chained) {
     const Packed wt = T.ffn[nl - 1];
-    rr_linear_args a = LA(M, ncur);
-    a.a1 = d; a.lda1 = L.out; a.k1 = L.out; set_w(a, wt); a.c = dx; a.ldc = ld_dx;
+    rr_linear_args a = LA(M, ffn_dx_rows(m, nl - 1));
+    a.a1 = d; a.lda1 = L.out; a.k1 = L.out; set_w(a, wt); a.c = dx[nl - 1]; a.ldc = ldx[nl - 1];
     lin(c, a, st);
   }
   for (int li = nl - 2; li >= 0; --li) {
     const rr_linear_w& Lh = m.ffn[li];
     const float* y = S.hs[li + 1];                       // drop(relu(.)) output of this layer
     {
-      rr_wgrad_args w = WA(M, Lh.out, dx, ld_dx, G.w[RR_G_FFN0 + li], Lh.in, G.b[RR_G_FFN0 + li], 0);
+      rr_wgrad_args w = WA(M, Lh.out, dx[li + 1], ldx[li + 1], G.w[RR_G_FFN0 + li], Lh.in, G.b[RR_G_FFN0 + li], 0);
       w.mask = y; w.ld_mask = S.ld_hs[li + 1]; w.mask_scale = ks;
       w.x1 = S.hs[li]; w.ldx1 = S.ld_hs[li]; w.k1 = Lh.in;
       wgrad(c, w);
     }
-    const int nin = ffn_dx_rows(m, li);
-    float* dn = c.alloc(M, r4(nin));
+    if (chained) continue;
     const Packed wt = T.ffn[li];
-    rr_linear_args a = LA(M, nin);
-    a.a1 = dx; a.lda1 = ld_dx; a.k1 = Lh.out; a.a_mask = y; a.ld_mask = S.ld_hs[li + 1]; a.mask_scale = ks;
-    set_w(a, wt); a.c = dn; a.ldc = r4(nin);
+    rr_linear_args a = LA(M, ffn_dx_rows(m, li));
+    a.a1 = dx[li + 1]; a.lda1 = ldx[li + 1]; a.k1 = Lh.out; a.a_mask = y; a.ld_mask = S.ld_hs[li + 1]; a.mask_scale = ks;
+    set_w(a, wt); a.c = dx[li]; a.ldc = ldx[li];
     lin(c, a, st);
-    dx = dn;
-    ld_dx = r4(nin);
   }
-  *ld_out = ld_dx;
-  return dx;
+  *ld_out = ldx[0];
+  return dx[0];
 }
 
 void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const float* dout, const rr_grads& G) {
@@ -985,6 +1041,7 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
     c.f16 = (v >> 1) == 2;
     c.ntr = c.namax = 0; c.amax_base = nullptr;
     c.train = (v & 1) != 0;
+    c.ffn_chain = true;
     Plan P;
     memset(&P, 0, sizeof(P));
     forward_all(c, *model, *step, P);
@@ -1010,6 +1067,7 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.ntr = c.namax = 0; c.amax_base = nullptr;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
+  c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1048,6 +1106,7 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.ntr = c.namax = 0; c.amax_base = nullptr;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
+  c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1081,6 +1140,7 @@ int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags,
   c.ntr = c.namax = 0; c.amax_base = nullptr;
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
+  c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   c.s.main = c.s.side = c.s.aux = nullptr;
   c.cur = nullptr;
   Plan P;

@@ -486,6 +486,13 @@ class SplitGemm:
     f16 = os.environ.get("RR_F16X2", "0") not in ("", "0")
 
 
+class FfnChain:
+    """The FFN head and its input-gradient chain as ONE launch each inside the step plans (rr_ffn_chain_f32, csrc/ffn.hip; bit-identical
+    to the per-layer launches this mirror issues).  enabled = False (or RR_NO_FFN_CHAIN=1 in the environment) makes the plans
+    issue the layers one by one as well: an A/B knob."""
+    enabled = True
+
+
 class LinW:
     """One nn.Linear's tensors plus lazily transposed copies for the input-gradient GEMM.
     big: its GEMMs run over atoms / bonds (the FFN head runs over molecules and stays on the f32 path)."""
@@ -1058,7 +1065,8 @@ class StepPlan:
         return ((0 if SideStream.enabled else _lib.RR_PLAN_NO_SIDE_STREAM) | (0 if AuxStream.enabled else _lib.RR_PLAN_NO_AUX_STREAM) |
                 (0 if SplitGemm.enabled else _lib.RR_PLAN_F32_GEMM) | (_lib.RR_PLAN_AUX_BACKWARD if AuxStream.backward else 0) |
                 (_lib.RR_PLAN_TRAIN if (train and not os.environ.get("RR_NO_TRAIN_PACK")) else 0) |
-                (_lib.RR_PLAN_F16X2_GEMM if (SplitGemm.enabled and SplitGemm.f16) else 0))
+                (_lib.RR_PLAN_F16X2_GEMM if (SplitGemm.enabled and SplitGemm.f16) else 0) |
+                (0 if FfnChain.enabled else _lib.RR_PLAN_NO_FFN_CHAIN))
 
 
 class ReactionModelFn(torch.autograd.Function):
