@@ -15,6 +15,7 @@
 // forward chain is linear_rowdot_kernel's 16-lane dot product with its shuffle tree.  tests/test_gpu_ffn.py holds it to
 // torch.equal against the per-layer path.
 #include "rr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -112,49 +113,72 @@ __global__ void __launch_bounds__(64 * NW) ffn_chain_kernel(const FfnParams P) {
     }
     const int N = S.n_out, K = S.n_in;
     const int T = (N + 15) / 16, nk = f_r16(K) / 16;
-    // this wave's tiles; a tile index past T is clamped (its loads stay in bounds, its results are dropped)
-    const float* wp[NTW];
+    // this wave's tiles: w, w + NW, ... below T (uniform count ntw: the first T % NW waves own one more than the others)
+    int ntw = 0;
 #pragma unroll
-    for (int g = 0; g < NTW; ++g) {
-      int t = wave + g * NW;
-      t = t < T ? t : T - 1;
-      int n = t * 16 + fr;
-      n = n < N ? n : N - 1;                     // (the packed weight has exactly N rows)
-      wp[g] = S.w + static_cast<int64_t>(n) * S.ldw + 4 * fkq;
-    }
+    for (int g = 0; g < NTW; ++g) ntw += (wave + g * NW < T) ? 1 : 0;
     f32x4 acc[NTW];
 #pragma unroll
     for (int g = 0; g < NTW; ++g) acc[g] = f32x4(0.f);
-    f32x4 wf[FPF][NTW];
-#pragma unroll
-    for (int p = 0; p < FPF; ++p) {
-      if (p < nk) {
-#pragma unroll
-        for (int g = 0; g < NTW; ++g) wf[p][g] = f_ldg4(wp[g] + 16 * p);
-      }
-    }
     const float* arow = cur + fr * pitch + 4 * fkq;
-    for (int kt0 = 0; kt0 < nk; kt0 += FPF) {
+    // The k-loop, compiled once per tile count NA so that it is straight-line code: weight fragments FPF k-tiles ahead in
+    // registers, every load UNCONDITIONAL (a k-tile index past the end is clamped: a harmless re-read of the last one) - a load
+    // under a branch, even a uniform one, is waited for with vmcnt(0) at the join, which puts a full L2 round trip in front of
+    // every k-tile's MFMAs (the first version: 35 us per launch).
+    auto gemm = [&](auto na_c) {
+      constexpr int NA = decltype(na_c)::value;
+      const float* wp[NA];
+#pragma unroll
+      for (int g = 0; g < NA; ++g) {
+        int n = (wave + g * NW) * 16 + fr;
+        n = n < N ? n : N - 1;                   // (the packed weight has exactly N rows)
+        wp[g] = S.w + static_cast<int64_t>(n) * S.ldw + 4 * fkq;
+      }
+      f32x4 wf[FPF][NA];
 #pragma unroll
       for (int p = 0; p < FPF; ++p) {
-        const int kt = kt0 + p;
-        if (kt < nk) {                           // (uniform)
-          const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 16 * kt);
-          f32x4 w_now[NTW];
+        const int kl = p < nk ? p : nk - 1;
 #pragma unroll
-          for (int g = 0; g < NTW; ++g) w_now[g] = wf[p][g];
-          if (kt + FPF < nk) {
+        for (int g = 0; g < NA; ++g) wf[p][g] = f_ldg4(wp[g] + 16 * kl);
+      }
+      auto ktile = [&](int kt, const f32x4 (&w_now)[NA]) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 16 * kt);
 #pragma unroll
-            for (int g = 0; g < NTW; ++g) wf[p][g] = f_ldg4(wp[g] + 16 * (kt + FPF));
-          }
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int g = 0; g < NA; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_now[g][j], af[j], acc[g], 0, 0, 0);
+        }
+      };
+      int kt0 = 0;
+      for (; kt0 + FPF <= nk; kt0 += FPF) {      // whole groups of FPF k-tiles
 #pragma unroll
-            for (int g = 0; g < NTW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_now[g][j], af[j], acc[g], 0, 0, 0);
-          }
+        for (int p = 0; p < FPF; ++p) {
+          const int kt = kt0 + p;
+          f32x4 w_now[NA];
+#pragma unroll
+          for (int g = 0; g < NA; ++g) w_now[g] = wf[p][g];
+          const int kl = kt + FPF < nk ? kt + FPF : nk - 1;
+#pragma unroll
+          for (int g = 0; g < NA; ++g) wf[p][g] = f_ldg4(wp[g] + 16 * kl);
+          asm volatile("" ::: "memory");         // the refill is ISSUED here, FPF k-tiles ahead of its use (left alone the
+          ktile(kt, w_now);                      // scheduler sinks it to just in front of that use to save registers)
         }
       }
-    }
+#pragma unroll
+      for (int p = 0; p < FPF - 1; ++p) {        // the last nk % FPF k-tiles: their fragments are in flight or here, no loads left
+        if (kt0 + p < nk) {
+          f32x4 w_now[NA];
+#pragma unroll
+          for (int g = 0; g < NA; ++g) w_now[g] = wf[p][g];
+          ktile(kt0 + p, w_now);
+        }
+      }
+    };
+    if (ntw == NTW) gemm(std::integral_constant<int, NTW>{});
+    else if (NTW >= 2 && ntw == NTW - 1) gemm(std::integral_constant<int, (NTW >= 2 ? NTW - 1 : 1)>{});
+    else if (NTW >= 3 && ntw == NTW - 2) gemm(std::integral_constant<int, (NTW >= 3 ? NTW - 2 : 1)>{});
+    else if (NTW >= 4 && ntw == NTW - 3) gemm(std::integral_constant<int, (NTW >= 4 ? NTW - 3 : 1)>{});
+    else if (NTW >= 5 && ntw == NTW - 4) gemm(std::integral_constant<int, (NTW >= 5 ? NTW - 4 : 1)>{});
     // ---- epilogue: a lane holds columns n .. n+3 (n = 16 t + 4 fkq) of row fr per tile
     const bool last = s + 1 == a.n_stages;
     const int kp_next = last ? 0 : f_r16(a.stage[s + 1].n_in);   // the next stage reads [0, kp_next) of its input rows

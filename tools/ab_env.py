@@ -15,6 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench  # noqa: E402
 from reactranker_amd import functions as Fn  # noqa: E402
+from reactranker_amd import loss as RL  # noqa: E402
 
 
 def main():
@@ -41,6 +42,7 @@ def main():
             # (Python-side switches: plan flags.)  Three exact bf16 terms are the default arithmetic (round 5); a variant that
             # names RR_F16X2 runs the opt-in two-f16-term form
             Fn.SplitGemm.f16 = "RR_F16X2" in ks
+            RL.FusedStep.enabled = "NOFUSEDLOSS" not in ks   # loss + d loss / d score in one launch (loss.FusedStep)
             Fn.SideStream.enabled = "NOSIDE" not in ks
             Fn.AuxStream.enabled = "NOAUX" not in ks
             Fn.AuxStream.backward = "AUXBWD" in ks         # reactant-encoder backward on the aux stream (RR_PLAN_AUX_BACKWARD)

@@ -14,7 +14,7 @@ if "--mark" in sys.argv:                                   # e.g. --mark ranking
     key = sys.argv[sys.argv.index("--mark") + 1]
     marks = [e[0] for e in ev if key in e[2]]
 else:
-    marks = [e[0] for e in ev if "listmle_fwd" in e[2] or "listnet_kernel" in e[2] or "ranknet_fwd" in e[2] or "evidential_kernel" in e[2]]
+    marks = [e[0] for e in ev if "listmle_fwd" in e[2] or "listmle_step" in e[2] or "listnet_kernel" in e[2] or "ranknet_fwd" in e[2] or "evidential_kernel" in e[2]]
 if "--marks-per-step" in sys.argv:
     marks = marks[::int(sys.argv[sys.argv.index("--marks-per-step") + 1])]
 lo, hi = marks[-1 - back], marks[-back]
