@@ -613,9 +613,7 @@ constexpr int RR_MAX_PACK_DEV = RR_MAX_PACK;
 struct PackMany {
   rr_pack_desc d[RR_MAX_PACK_DEV];
 };
-__global__ void __launch_bounds__(256) pack_weights_kernel(const PackMany P) {
-  const rr_pack_desc& q = P.d[blockIdx.y];
-  if (q.split) return;                                 // pack_split_kernel's
+__device__ __forceinline__ void pack_plain_desc(const rr_pack_desc& q) {
   const int k1p = r16(q.k1), ldd = r16(q.k1) + r16(q.k2);
   const int64_t total = static_cast<int64_t>(q.rows) * ldd;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -629,6 +627,11 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackMany P) {
       v = q.transpose ? q.src[static_cast<int64_t>(lc) * q.ld_src + q.c0 + r] : q.src[static_cast<int64_t>(r) * q.ld_src + q.c0 + lc];
     q.dst[e] = v;
   }
+}
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackMany P) {
+  const rr_pack_desc& q = P.d[blockIdx.y];
+  if (q.split) return;                                 // pack_split_kernel's
+  pack_plain_desc(q);
 }
 
 // ------------------------------------------------------------------------ split path (3 x bf16 terms, 6 products)
@@ -1520,9 +1523,14 @@ __global__ void __launch_bounds__(1024) pack_scale_kernel(const PackMany P) {
   }
 }
 
+// (one launch packs EVERY weight of a pass: the f32 panels of the FFN head as well - blockIdx.y picks the weight, its
+// `split` the layout; a second launch for the plain ones cost a ~7 us kernel + a launch boundary in front of every forward)
 __global__ void __launch_bounds__(256) pack_split_kernel(const PackMany P) {
   const rr_pack_desc& q = P.d[blockIdx.y];
-  if (!q.split) return;
+  if (!q.split) {
+    pack_plain_desc(q);
+    return;
+  }
   const int64_t total = static_cast<int64_t>((r32(q.k1) + r32(q.k2)) / SK) * split_nt(q.rows) * 512;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   float S = 1.f;
@@ -2670,16 +2678,16 @@ int rr_pack_weights_f32(const rr_pack_desc* descs, int n, rr_stream_t stream) {
     if (total > (q.split ? biggest_split : biggest)) (q.split ? biggest_split : biggest) = total;
   }
   for (int i = n; i < RR_MAX_PACK; ++i) P.d[i] = descs[0];
-  if (biggest > 0) {
-    dim3 grid(static_cast<unsigned>(rr_grid_for(biggest, 256, 64)), static_cast<unsigned>(n));
-    pack_weights_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
-  }
-  if (biggest_split > 0) {
+  if (biggest_split > 0) {                             // split weights present: ONE launch packs both layouts
     bool any_f16 = false;
     for (int i = 0; i < n; ++i) any_f16 = any_f16 || descs[i].split == 2;
     if (any_f16) pack_scale_kernel<<<dim3(PACK_SCALE_BLOCKS, static_cast<unsigned>(n)), 1024, 0, static_cast<hipStream_t>(stream)>>>(P);
-    dim3 grid(static_cast<unsigned>(rr_grid_for(biggest_split, 256, 64)), static_cast<unsigned>(n));
+    const int64_t work = biggest_split > biggest ? biggest_split : biggest;
+    dim3 grid(static_cast<unsigned>(rr_grid_for(work, 256, 64)), static_cast<unsigned>(n));
     pack_split_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
+  } else if (biggest > 0) {
+    dim3 grid(static_cast<unsigned>(rr_grid_for(biggest, 256, 64)), static_cast<unsigned>(n));
+    pack_weights_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(P);
   }
   return rr_launch_status();
 }

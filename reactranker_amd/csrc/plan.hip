@@ -734,6 +734,14 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     RR_TRY(c, rr_gather_sum_dropmask_f32(d_msg, g.nB, H, S.z1_u, H, bmap_t, gu.nB, bmap_t_cols, H, p, S.seed0, ks, dz1_u, H, st));
   else
     RR_TRY(c, rr_gather_sum_masked_f32(d_msg, S.msgs[1], g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, ks, dz1_u, H, st));
+  // the prefix's W_h weight gradient needs dz1_u only: issued here, before the main stream's gather / axpby below, so that the
+  // weight-gradient stream's tail (this one, then W_i's) ends ~40 us earlier in front of the optimizer (same order among the
+  // weight gradients, so the accumulation order - and every bit - is unchanged)
+  {
+    rr_wgrad_args w = WA(gu.nB, H, dz1_u, H, G.wh, H, G.bh, wh_started);
+    w.x1 = S.a0_u; w.ldx1 = H; w.k1 = H; w.x1_idx = gu.b2a; w.x1_sub = S.msg0_u; w.ldx1_sub = H; w.x1_sub_idx = gu.b2revb;
+    wgrad(c, w);
+  }
   float* d_inp_u = c.alloc(gu.nB, H);
   // d_inp_u is accumulated in place twice below (axpby, the ReLU backward of msg0): its bound for the W_i weight gradient is
   // found by a pass AFTER the last write (amax_of in wgrad()), never by the gather that writes its first summand
@@ -743,11 +751,6 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     RR_TRY(c, rr_axpby_f32(1.0f, d_inp_u, 1.0f, dz1_u, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
   } else {
     RR_TRY(c, rr_axpby_f32(1.0f, dz1_u, 0.0f, nullptr, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
-  }
-  {
-    rr_wgrad_args w = WA(gu.nB, H, dz1_u, H, G.wh, H, G.bh, wh_started);
-    w.x1 = S.a0_u; w.ldx1 = H; w.k1 = H; w.x1_idx = gu.b2a; w.x1_sub = S.msg0_u; w.ldx1_sub = H; w.x1_sub_idx = gu.b2revb;
-    wgrad(c, w);
   }
   float* d_min_u = c.alloc(gu.nB, H);
   float* part_u = c.alloc(rr_linear_colsum_rows(gu.nB), r4(H));

@@ -2,7 +2,7 @@
 atom rows, H = 300), for same-box A/B of kernel variants: RR_LIB_PATH=build/variants/lib_X.so python tools/linear_modes_bench.py
 Prints one line per launch form: microseconds per launch (median of 5 x 20 back-to-back launches)."""
 import os, sys, statistics, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reactranker_amd import functions as Fn
 from reactranker_amd._lib import lib
 dev = "cuda"
