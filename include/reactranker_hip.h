@@ -691,6 +691,11 @@ int rr_comm_unique_id(void* id);
 int rr_comm_init_rank(rr_comm_t* comm, int n_ranks, const void* id, int rank);
 int rr_comm_destroy(rr_comm_t comm);
 int rr_allreduce_f32(float* buf, int64_t n, float scale, rr_comm_t comm, rr_stream_t stream);
+/* The same result as two collectives (ABI revision 8): reduce-scatter + all-gather, in place, over the largest prefix of the
+ * bucket that divides by the communicator's rank count, the remaining < n_ranks elements through an all-reduce; then the
+ * scale.  For the 3.16 / 12.1 MB buckets on xGMI's point-to-point links; which form is faster is a
+ * measurement for an 8-GPU node - rr_allreduce_f32 stays the default.  With 2 ranks the bits equal rr_allreduce_f32's. */
+int rr_allreduce_rsag_f32(float* buf, int64_t n, float scale, rr_comm_t comm, rr_stream_t stream);
 
 /* Bond-to-bond backward table (HOST pointers), derived from the tables above.  The adjoint of
  *   message[b] = a_message[b2a[b]] - message[b2revb[b]],  a_message[a] = sum_k message[a2b[a,k]]   (models/mpn.py:89-92)

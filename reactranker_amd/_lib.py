@@ -224,6 +224,7 @@ _SIGS = {
     "rr_comm_init_rank": (i32, [C.POINTER(C.c_void_p), i32, C.c_void_p, i32]),
     "rr_comm_destroy": (i32, [C.c_void_p]),
     "rr_allreduce_f32": (i32, [c_f32p, i64, f32, C.c_void_p, c_stream]),
+    "rr_allreduce_rsag_f32": (i32, [c_f32p, i64, f32, C.c_void_p, c_stream]),
     "rr_derive_bond_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, i32,
                                     C.c_void_p, C.c_void_p]),
     "rr_derive_tables": (i32, [C.c_void_p, C.c_void_p, C.c_void_p, i64, i64, i32, C.c_void_p, i64, C.c_void_p,

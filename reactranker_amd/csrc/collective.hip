@@ -21,6 +21,9 @@ typedef int (*get_id_fn)(UniqueId*);
 typedef int (*init_rank_fn)(void**, int, UniqueId, int);
 typedef int (*destroy_fn)(void*);
 typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*reduce_scatter_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*comm_int_fn)(const void*, int*);
 
 struct Rccl {
   bool tried = false, ok = false;
@@ -29,6 +32,9 @@ struct Rccl {
   init_rank_fn init_rank = nullptr;
   destroy_fn destroy = nullptr;
   allreduce_fn allreduce = nullptr;
+  reduce_scatter_fn reduce_scatter = nullptr;             // optional: the two-phase form of rr_allreduce_rsag_f32
+  all_gather_fn all_gather = nullptr;
+  comm_int_fn comm_count = nullptr, comm_rank = nullptr;
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -53,6 +59,10 @@ const Rccl& rccl() {
       g_rccl.init_rank = reinterpret_cast<init_rank_fn>(dlsym(h, "ncclCommInitRank"));
       g_rccl.destroy = reinterpret_cast<destroy_fn>(dlsym(h, "ncclCommDestroy"));
       g_rccl.allreduce = reinterpret_cast<allreduce_fn>(dlsym(h, "ncclAllReduce"));
+      g_rccl.reduce_scatter = reinterpret_cast<reduce_scatter_fn>(dlsym(h, "ncclReduceScatter"));
+      g_rccl.all_gather = reinterpret_cast<all_gather_fn>(dlsym(h, "ncclAllGather"));
+      g_rccl.comm_count = reinterpret_cast<comm_int_fn>(dlsym(h, "ncclCommCount"));
+      g_rccl.comm_rank = reinterpret_cast<comm_int_fn>(dlsym(h, "ncclCommUserRank"));
       g_rccl.ok = g_rccl.get_id && g_rccl.init_rank && g_rccl.destroy && g_rccl.allreduce;
     }
     if (!g_rccl.ok) g_rccl.how = 0;
@@ -111,6 +121,39 @@ int rr_allreduce_f32(float* buf, int64_t n, float scale, rr_comm_t comm, rr_stre
   if (!r.ok) return RR_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (r.allreduce(buf, buf, static_cast<size_t>(n), kNcclFloat32, kNcclSum, comm, s) != 0) return RR_ERR_LAUNCH;
+  if (scale != 1.0f) {
+    const bool vec = rr_aligned16(buf);
+    scale_kernel<<<rr_grid_for(vec ? (n + 3) / 4 : n, 256), 256, 0, s>>>(buf, vec ? n / 4 : 0, n, scale);
+    return rr_launch_status();
+  }
+  return RR_OK;
+}
+
+// The same sum as TWO collectives - reduce-scatter, then all-gather, in place - over the largest prefix of the bucket that
+// divides by the rank count; the < n_ranks elements behind it go through a (tiny) all-reduce.  SURVEY.md section 5: xGMI is
+// point-to-point (7 links per GPU), so for the 3-12 MB gradient bucket a direct reduce-scatter + all-gather lets every rank
+// own 1/R of the reduction and use all its links at once, where a ring all-reduce is bound by one link.  Which of the two
+// RCCL runs faster at these sizes is a measurement for an 8-GPU node (none was available to any round so far): this entry
+// point exists so that the measurement is one flag away, rr_allreduce_f32 stays the default.  Summation order: element i of
+// chunk c is reduced by RCCL's reduce-scatter for the rank that owns c - with 2 ranks the same bits as the all-reduce (a + b),
+// with more ranks the order inside RCCL may differ from its all-reduce algorithm's (both are fixed per communicator).
+int rr_allreduce_rsag_f32(float* buf, int64_t n, float scale, rr_comm_t comm, rr_stream_t stream) {
+  RR_CHECK_ARG(buf && comm && n >= 0);
+  if (n == 0) return RR_OK;
+  const Rccl& r = rccl();
+  if (!r.ok) return RR_ERR_UNSUPPORTED;
+  if (!r.reduce_scatter || !r.all_gather || !r.comm_count || !r.comm_rank) return RR_ERR_UNSUPPORTED;
+  int R = 0, me = -1;
+  if (r.comm_count(comm, &R) != 0 || r.comm_rank(comm, &me) != 0 || R < 1 || me < 0 || me >= R) return RR_ERR_LAUNCH;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t chunk = n / R, body = chunk * R;
+  if (chunk > 0) {
+    float* mine = buf + static_cast<int64_t>(me) * chunk;              // in-place forms: recv = send + rank * count
+    if (r.reduce_scatter(buf, mine, static_cast<size_t>(chunk), kNcclFloat32, kNcclSum, comm, s) != 0) return RR_ERR_LAUNCH;
+    if (r.all_gather(mine, buf, static_cast<size_t>(chunk), kNcclFloat32, comm, s) != 0) return RR_ERR_LAUNCH;
+  }
+  if (body < n && r.allreduce(buf + body, buf + body, static_cast<size_t>(n - body), kNcclFloat32, kNcclSum, comm, s) != 0)
+    return RR_ERR_LAUNCH;
   if (scale != 1.0f) {
     const bool vec = rr_aligned16(buf);
     scale_kernel<<<rr_grid_for(vec ? (n + 3) / 4 : n, 256), 256, 0, s>>>(buf, vec ? n / 4 : 0, n, scale);

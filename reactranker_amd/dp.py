@@ -9,6 +9,7 @@ local_count / global_count so the reduced gradient equals the single-process one
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional, Tuple
 
 import torch
@@ -26,6 +27,7 @@ class GradBucket:
     """Flat fp32 gradient bucket (3.16 MB at H=300: latency-bound, so exactly one collective)."""
 
     profile = False          # bench.py: record a HIP-event pair around every collective (class-wide switch)
+    algo = None              # None -> $RR_ALLREDUCE or "allreduce"; "rsag" = reduce-scatter + all-gather (see _collective)
     events: List = []        # [(start, end)] on the compute stream, filled while `profile` is on
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
@@ -74,6 +76,26 @@ class GradBucket:
         if not GradBucket._attached:
             Fn.GradSink.lookup = None
 
+    def _collective(self, group) -> None:
+        """flat <- sum over ranks.  Default: ONE all-reduce (latency-bound at 3-12 MB: SURVEY.md section 8e).  GradBucket.algo =
+        "rsag" (or RR_ALLREDUCE=rsag in the environment) issues the same sum as reduce-scatter + all-gather over the largest
+        prefix that divides by the world size (+ a tiny all-reduce for the < world remaining elements): on xGMI's point-to-point
+        links every rank then owns 1/R of the reduction (rr_allreduce_rsag_f32 is the C-ABI twin).  Which
+        is faster is a measurement for an 8-GPU node; with 2 ranks the two give the same bits.  Backends without
+        reduce_scatter_tensor (gloo) keep the all-reduce."""
+        algo = GradBucket.algo or os.environ.get("RR_ALLREDUCE", "allreduce")
+        world = dist.get_world_size(group)
+        if algo == "rsag" and self.flat.is_cuda and dist.get_backend(group) == "nccl" and self.flat.numel() >= world:
+            chunk = self.flat.numel() // world
+            body = self.flat[:chunk * world]
+            mine = body[dist.get_rank(group) * chunk:(dist.get_rank(group) + 1) * chunk]
+            dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=group)
+            dist.all_gather_into_tensor(body, mine, group=group)
+            if chunk * world < self.flat.numel():
+                dist.all_reduce(self.flat[chunk * world:], op=dist.ReduceOp.SUM, group=group)
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
     def allreduce(self, local_weight: float = 1.0, group=None) -> None:
         """grad <- sum_ranks(local_weight_r * grad_r).  With equal shards pass 1/world."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -107,11 +129,11 @@ class GradBucket:
         if GradBucket.profile and self.flat.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self._collective(group)
             e1.record()
             GradBucket.events.append((e0, e1))
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self._collective(group)
         if not inplace:
             torch._foreach_copy_([p.grad for p in self.params], list(self._views))
 

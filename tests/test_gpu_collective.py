@@ -14,6 +14,7 @@ from reactranker_amd._lib import check, lib, ptr, stream
 def test_allreduce_argument_checks_need_no_gpu():
     l = lib()
     assert l.rr_allreduce_f32(None, 0, 1.0, None, None) == -1            # RR_ERR_ARG: null buffer / communicator
+    assert l.rr_allreduce_rsag_f32(None, 0, 1.0, None, None) == -1
     assert l.rr_comm_destroy(None) == -1
     assert l.rr_comm_init_rank(None, 1, None, 0) == -1
 
@@ -36,6 +37,12 @@ def test_allreduce_over_a_one_rank_communicator(n, scale):
         side.synchronize()
         assert torch.equal(y, x * scale)
         check(l.rr_allreduce_f32(ptr(y), 0, 1.0, comm, stream()), "empty buffer")
+        # the two-collective form (reduce-scatter + all-gather over the prefix that divides by the rank count, ABI revision 8):
+        # same result on the same communicator
+        z = x.clone()
+        check(l.rr_allreduce_rsag_f32(ptr(z), n, scale, comm, stream()), "rr_allreduce_rsag_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(z, y)
     finally:
         check(l.rr_comm_destroy(comm), "rr_comm_destroy")
 
@@ -61,3 +68,35 @@ def test_rccl_already_in_the_process_is_used_as_is():
     env.pop("LD_PRELOAD")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "RC 0 HOW" in out.stdout, (out.stdout, out.stderr[-2000:])          # nothing preloaded: torch's copy, or dlopen
+
+
+@pytest.mark.gpu
+def test_gradient_bucket_rsag_over_a_one_rank_rccl_group(tmp_path):
+    """dp.GradBucket with algo = "rsag" over torch.distributed's nccl (= RCCL) backend: the reduce-scatter + all-gather path runs
+    on a real communicator (one rank on a one-GPU box: the sum of one is itself) and leaves the gradients where autograd
+    expects them.  A fresh process, because a process group can be initialised only once."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from reactranker_amd import dp\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "torch.cuda.set_device(0)\n"
+        "m = torch.nn.Linear(37, 5).cuda()\n"
+        "b = dp.GradBucket(m.parameters())\n"
+        "m(torch.randn(3, 37, device='cuda')).sum().backward()\n"
+        "ref = [p.grad.clone() for p in m.parameters()]\n"
+        "dp.GradBucket.algo = 'rsag'\n"
+        "b.flat.copy_(torch.cat([g.reshape(-1) for g in ref]))\n"
+        "b._collective(None)\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(b.flat, torch.cat([g.reshape(-1) for g in ref]))\n"
+        "print('RSAG OK', dist.get_backend())\n"
+        "dist.destroy_process_group()\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "RSAG OK nccl" in out.stdout, (out.stdout, out.stderr[-3000:])
