@@ -863,7 +863,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // an interior step reads columns [s*SK, (s+1)*SK) <= k of its row - or of rr_zero_row when the row is missing: the
   // segment (plus one step of slack for the prefetch) must fit inside that array
   static_assert(RR_ZERO_ROW % SK == 0 && RR_ZERO_ROW >= 2 * SK, "rr_zero_row must hold whole k-steps");
-  const bool fastx_ok = FASTX && a.k1 + SK <= RR_ZERO_ROW && a.k2 + SK <= RR_ZERO_ROW;
+  // (the EPI 0 / 1 instantiations of the 12-wave geometry are only launched with segments that fit - launch_split_one sends
+  // longer ones to their twins EPI 2 / 3, which keep the generic loader - so their select-per-element loader is dead code:
+  // fewer live scalars and pointers in kernels that have none to spare.  Measured on
+  // the persistent form <19,19,0,12,0>: 12 -> 2 spilled registers, -3 ... -5 % per launch at 71k rows, -0.7 % on the step)
+  constexpr bool LEAN_ONLY = FASTX && WAVES == 12 && EPI < 2;
+  const bool fastx_ok = FASTX && (LEAN_ONLY || (a.k1 + SK <= RR_ZERO_ROW && a.k2 + SK <= RR_ZERO_ROW));
   const float* xb1 = (rowp1 != nullptr ? rowp1 : rr_zero_row) + fkq * 8;
   const float* xb2 = (rowp2 != nullptr ? rowp2 : rr_zero_row) + fkq * 8;
   const float* const sb1 = (subp != nullptr ? subp : rr_zero_row) + fkq * 8;
@@ -909,7 +914,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
           rs[slot][1] = ldg4(q + 4);
         }
       } else {                                         // last step of a segment: chunks past its end read zeros
-        const int kl = off + fkq * 8, ks = s1 ? a.k1 : a.k2;
+        int fq = fkq;                                  // (opaque: these selects are per-lane loop invariants - left alone they are
+        if (CAN_PERSIST) asm volatile("" : "+v"(fq));  // hoisted out of the block loop, kept live across the k-loop and spilled)
+        const int kl = off + fq * 8, ks = s1 ? a.k1 : a.k2;
         ra[slot][0] = ldg4(kl < ks ? p : rr_zero_row);
         ra[slot][1] = ldg4(kl + 4 < ks ? p + 4 : rr_zero_row);
         if (MODE == 1) {
@@ -1107,7 +1114,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       rr_glds16(p, dst);
       rr_glds16(p + 4, dst + 1024);
     } else {
-      const int kl = fkq * 8, ks = s1 ? a.k1 : a.k2;
+      int fq = fkq;
+      asm volatile("" : "+v"(fq));                     // (see issue_x)
+      const int kl = fq * 8, ks = s1 ? a.k1 : a.k2;
       rr_glds16(kl < ks ? p : rr_zero_row, dst);
       rr_glds16(kl + 4 < ks ? p + 4 : rr_zero_row, dst + 1024);
     }
@@ -1227,7 +1236,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // the rare combination of column sums WITH epilogue arithmetic keeps the accumulator-layout code below.
   const bool plain_epi = !has_bias && a.residual == nullptr && !relu && P.drop_thr == 0u && prow == nullptr && !mb_on;
   bool done = false;
-  if (RS_EPI && EPI == 1 && (!cs_on || plain_epi)) {
+  if (RS_EPI && (EPI & 1) == 1 && (!cs_on || plain_epi)) {
     done = true;
     if (cs_on) {
 #pragma unroll
@@ -1336,7 +1345,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   if (!done) {
     // (with RR_EPI_MODE 1 the 12-wave forward forms that carry a residual take the row-contiguous epilogue above: this
     // instantiation then never sees one, and its register ring is not needed)
-    constexpr bool MAY_RES = !(RR_EPI_MODE == 1 && WAVES == 12 && (MODE == 0 || MODE == 1) && EPI == 0);
+    constexpr bool MAY_RES = !(RR_EPI_MODE == 1 && WAVES == 12 && (MODE == 0 || MODE == 1) && (EPI & 1) == 0);
     const bool res_ok = MAY_RES && rrow != nullptr;
     const float* rbase = res_ok ? rrow : dummy;
     constexpr int D = MAY_RES ? 4 : 0;
@@ -2528,7 +2537,12 @@ template <int NTP, int NT, int MODE, int WAVES, bool F16>
 int launch_split_one(const LinearParams& P, hipStream_t s) {
   if (WAVES == 12 && (MODE == 0 || MODE == 1)) {       // (the dX forms, MODE 2 / 3, never carry a residual)
     const bool rs = RR_EPI_MODE == 2 || (RR_EPI_MODE == 1 && P.a.residual != nullptr);
-    if (rs) return launch_split_epi<NTP, NT, MODE, WAVES, (WAVES == 12 && (MODE == 0 || MODE == 1)) ? 1 : 0, F16>(P, s);
+    // EPI 0 / 1: the epilogue (accumulator layout / row-contiguous) with the lean loader only; segments past the zero row
+    // (K > 992: no configuration of the model) go to the twins EPI 2 / 3, which keep the generic loader
+    const bool lean = P.a.k1 + SK <= RR_ZERO_ROW && P.a.k2 + SK <= RR_ZERO_ROW;
+    constexpr int E1 = (WAVES == 12 && (MODE == 0 || MODE == 1)) ? 1 : 0, G = (WAVES == 12 && (MODE == 0 || MODE == 1)) ? 2 : 0;
+    if (!lean) return rs ? launch_split_epi<NTP, NT, MODE, WAVES, G + E1, F16>(P, s) : launch_split_epi<NTP, NT, MODE, WAVES, G, F16>(P, s);
+    if (rs) return launch_split_epi<NTP, NT, MODE, WAVES, E1, F16>(P, s);
   }
   return launch_split_epi<NTP, NT, MODE, WAVES, 0, F16>(P, s);
 }
