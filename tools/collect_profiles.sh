@@ -17,13 +17,15 @@ for f in $root/reactranker_amd/csrc/*.hip $root/reactranker_amd/csrc/*.cpp $root
 done
 cd /tmp && export TMPDIR=/tmp
 echo "[collect] stats pass"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -- python3 $root/bench.py --no-cpu-baseline --no-fwd-only --no-epoch --no-presets --no-f32-path > $out/${tag}_stats_bench.json 2> $out/${tag}_stats.err
+# a PURE plan-step profile (round-4 review item 7): the timed region only, no per-op event passes, no comparison legs - its
+# percentages are a training step's
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -- python3 $root/bench.py --plan-only --steps 30 --warmup 5 > $out/${tag}_stats_bench.json 2> $out/${tag}_stats.err
 cp $(find $out/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
 cp $(find $out/prof_stats -name "*domain_stats.csv" | head -1) $out/${tag}_bench_domain_stats.csv 2>/dev/null || true
 rm -rf $out/prof_stats
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "[collect] pmc pass $c"
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile --no-fwd-only --no-epoch --no-presets --no-f32-path > /dev/null 2> $out/${tag}_pmc_$c.err
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --plan-only --steps 6 --warmup 2 > /dev/null 2> $out/${tag}_pmc_$c.err
 done
 cd $root
 python3 tools/traffic_from_pmc.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/${tag}_traffic.json

@@ -6,7 +6,7 @@ tag=${1:-r03}
 root=$(pwd); out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $out/tl -- python3 $root/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-profile --no-fwd-only --no-epoch --no-presets --no-f32-path > /dev/null 2> $out/${tag}_tl.err
+rocprofv3 --kernel-trace --output-format csv -d $out/tl -- python3 $root/bench.py --plan-only --steps 12 --warmup 4 > /dev/null 2> $out/${tag}_tl.err
 cd $root
 python3 tools/step_timeline.py $(find $out/tl -name "*kernel_trace.csv" | head -1) ${2:-3} > $out/${tag}_step_timeline.txt
 rm -rf $out/tl
