@@ -262,10 +262,11 @@ def summarise(recs, traffic):
         n = sum(h[1] for h in hits)
         return round(sum(h[0] * h[1] for h in hits) / n) if n else None
     agg = {}
-    for key, flops, nbytes, e0, e1 in recs:
+    for rec in recs:                                      # (key, flops, bytes, start event, end event) or (key, flops, bytes, seconds)
+        key, flops, nbytes = rec[:3]
         a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
         a[0] += 1
-        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[1] += rec[3] if len(rec) == 4 else rec[3].elapsed_time(rec[4]) * 1e-3
         a[2] += flops
         a[3] += nbytes
     for k, (n, secs, fl, by) in agg.items():
@@ -603,30 +604,11 @@ def main():
     def cyc(off):
         return lambda i: pool[(off + i) % len(pool)]
 
-    # the warm-up steps are timed per launch for every heavy kernel, to find the dominant MFMA kernel; the timed
-    # region then carries events around that kernel and the gather kernel only (an event pair around all ~60
-    # heavy launches of a step costs ~4 % of the step)
-    dominant, top = None, []
     if world > 1:
         DP.GradBucket.profile = True                     # HIP events around the collective (reported under "dp")
-    if not args.no_profile:
-        Fn.Profiler.start()
     for i in range(args.warmup):
         R.train_step(pool[i % len(pool)])
     R.fence()
-    if not args.no_profile:
-        tot = {}
-        for key, flops, _, e0, e1 in Fn.Profiler.stop():
-            if flops:
-                tot[key] = tot.get(key, 0.0) + e0.elapsed_time(e1)
-        top = sorted(tot, key=lambda k: -rank_time(k, tot[k]))[:2]   # the two heaviest GEMM kernels carry events in the timed region
-        dominant = top[0] if top else None
-        # the profiled warm-up steps ran the per-op path; the timed region mostly runs the step plan, whose one big
-        # workspace has to come out of the caching allocator once (a fresh hipMalloc of ~2 GB is an ~80 ms step): two more
-        # untimed steps on that path
-        for i in range(2):
-            R.train_step(pool[(args.warmup + i) % len(pool)])
-        R.fence()
     DP.GradBucket.events.clear()
     # The timed region issues every step through the step plan (one native call per pass) and records NO kernel events:
     # `value` is the plan path only.  The live roofline timings come from an extra pass right behind it (below).
@@ -634,16 +616,37 @@ def main():
     elapsed, per_ms, last = R.timed(cyc(args.warmup), args.steps)
     records = []
     if not args.no_profile:
-        # in-situ pass: the same steps, same three streams overlapping, HIP events on the launch stream around every launch
-        # of the two heaviest GEMM kernels and the gather kernels.  A step that carries events runs the per-op path (~33 event
-        # pairs of ~14 us of stream time each, ~1.3 ms more than a plan step), which is why it is not part of `value`.
+        # in-situ pass ON THE SAME PATH: the same steps through the same step plans, same three streams overlapping, with
+        # RR_PLAN_TIME - the library records a HIP-event pair on the launch stream around every split-GEMM and gather-sum launch
+        # (rr_plan_timing_take).  ~5 us of stream time per timed launch (~45 per step), which is why it is not part of `value`.
         n_prof = max(2, min(6, args.steps // 5))
-        Fn.Profiler.start(only=[k for k in (*top, *GATHER_KEYS) if k])
-        for i in range(n_prof):
-            R.train_step(pool[(args.warmup + args.steps + i) % len(pool)])
-        R.fence()
-        records = Fn.Profiler.stop()
-        log(f"in-situ kernel timing pass done ({n_prof} steps, events on {top} + gathers)")
+
+        def timed_pass(kinds, modes, n):
+            Fn.StepPlan.select_timings(kinds, modes)
+            Fn.StepPlan.timing = True
+            try:
+                for i in range(n):
+                    R.train_step(pool[(args.warmup + args.steps + i) % len(pool)])
+                R.fence()
+            finally:
+                Fn.StepPlan.timing = False
+                Fn.StepPlan.select_timings()
+            return Fn.StepPlan.take_timings()
+        # every event pair costs its stream ~5 us and loosens the overlap between the streams (a step with all ~45 heavy
+        # launches timed reports 150 us for a kernel rocprofv3 sees at 177 us in the untimed step): rank the GEMM keys on two
+        # fully timed steps, then time ONE GEMM mode per pass, then the gathers
+        ranking = {}
+        for key, flops, _, secs in timed_pass(1, 15, 2):
+            ranking[key] = ranking.get(key, 0.0) + secs
+        order = sorted(ranking, key=lambda k: -ranking[k])
+        modes_done = []
+        for key in order[:2]:                             # dominant GEMM key and the runner-up: operand mode = third template value
+            mode = int(key.split(",")[2])
+            if mode not in modes_done:
+                modes_done.append(mode)
+                records += timed_pass(1, 1 << mode, n_prof)
+        records += timed_pass(6, 0, n_prof)               # both gather kinds
+        log(f"in-situ kernel timing passes done ({n_prof} plan steps each: GEMM modes {modes_done}, gathers; {len(records)} timed launches)")
     log(f"timed region done: {elapsed / max(1, args.steps) * 1e3:.2f} ms/step")
     loss_val = float(last.detach().sum().cpu()) if last is not None else float("nan")
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -735,10 +738,9 @@ def main():
         if roof["bound"] == "mfma" and "split" not in roof["kernel"]:
             roof["peak_at_load_clock"] = load_clock
         roof["traffic_source"] = traffic_src
-        roof["note"] = ("extra pass right behind the timed region (same steps, same model state, same three streams: the "
-                        "weight-gradient / reactant-encoder streams run concurrently with the main stream), HIP events on the "
-                        "launch stream around every launch of this kernel; the timed region itself carries no events and "
-                        "runs the step plan only")
+        roof["note"] = ("extra pass right behind the timed region on the SAME path (step plans with RR_PLAN_TIME: same steps, same "
+                        "model state, same three streams overlapping), HIP events on the launch stream around every launch of "
+                        "this kernel (rr_plan_timing_take); the timed region itself carries no events")
     # isolated pass: the same steps with every kernel serialised on one stream -> per-kernel quality
     roof_iso = roof_g_iso = None
     ktable_iso = {}

@@ -629,8 +629,11 @@ enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2,
                                         matrix instructions of the three-bf16-term path, 22 significant bits per operand); the
                                         plan finds every operand's largest magnitude itself (rr_amax_f32, one slot per tensor
                                         in the workspace).  Ignored with RR_PLAN_F32_GEMM; layout-changing (ABI revision 7). */
-       RR_PLAN_NO_FFN_CHAIN = 64 };  /* the FFN head's layers as separate launches instead of rr_ffn_chain_f32 (same results
+       RR_PLAN_NO_FFN_CHAIN = 64,    /* the FFN head's layers as separate launches instead of rr_ffn_chain_f32 (same results
                                         bit for bit, same workspace layout: an A/B knob; ABI revision 8) */
+       RR_PLAN_TIME = 128 };         /* measurement: HIP events on the launch stream around every split-GEMM and gather-sum launch
+                                        of this call, collected by rr_plan_timing_take (costs ~5 us of stream time per launch:
+                                        not for timed runs; ABI revision 8) */
 
 typedef struct rr_step {
   rr_graph p, r, u;
@@ -655,6 +658,24 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step);
 int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, rr_stream_t stream);
 int rr_reaction_backward(const rr_model* model, const rr_step* step, const float* dout, const rr_grads* grads, int flags,
                          rr_stream_t stream);
+
+/* Per-launch durations of the heavy kernels INSIDE a step plan (RR_PLAN_TIME): what bench.py's roofline object is made of, measured
+ * on the path `value` is measured on.  One record per rr_linear_f32 launch on the split path (M >= 8192) and per gather-sum launch. */
+typedef struct rr_plan_timing {
+  int kind;                /* 0 = rr_linear_f32 (split GEMM), 1 = rr_gather_sum_f32 / _padrow / _amax, 2 = rr_gather_sum_epi_f32 */
+  int mode;                /* GEMM: 0 plain, 1 subtract operand, 2 f32 mask, 3 sign-bit mask */
+  int64_t M;               /* GEMM rows / gather destination rows */
+  int64_t n_src;           /* gather: source rows */
+  int N, k1, k2;           /* GEMM: columns, segment widths; gather: N = H, k1 = table width K, k2 = addends */
+  int residual, c_pre, dz_out, bits_out, bits_in, mask;   /* which optional operands / outputs the launch carried (0 / 1) */
+  float us;                /* HIP-event time around the launch on its stream */
+} rr_plan_timing;
+/* Waits for the recorded launches of this process, copies up to max_n records (oldest first) and forgets them all; returns the count. */
+int rr_plan_timing_take(rr_plan_timing* out, int max_n);
+/* Which launches carry events under RR_PLAN_TIME: bit k of `kinds` = launches of kind k, bit m of `modes` = GEMMs of mode m (default:
+ * all).  Every event pair costs its stream ~5 us and loosens the overlap between the streams: timing ONE kernel key at a time keeps a
+ * step within ~1 % of an untimed one, and its durations at what rocprofv3 --kernel-trace reports for the untimed step. */
+int rr_plan_timing_select(int kinds, int modes);
 
 /* Where a step keeps an activation inside its workspace (ABI revision 6) - valid from rr_reaction_forward until the
  * workspace is reused; nothing is launched.  For hosts that want the encoder's outputs (atom hiddens, reaction vectors:

@@ -83,6 +83,14 @@ RR_G_FFN0 = 6
 RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
 RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM, RR_PLAN_AUX_BACKWARD, RR_PLAN_TRAIN, RR_PLAN_F16X2_GEMM = 1, 2, 4, 8, 16, 32
 RR_PLAN_NO_FFN_CHAIN = 64
+RR_PLAN_TIME = 128
+
+
+class PlanTiming(C.Structure):
+    _fields_ = [
+        ("kind", i32), ("mode", i32), ("M", i64), ("n_src", i64), ("N", i32), ("k1", i32), ("k2", i32),
+        ("residual", i32), ("c_pre", i32), ("dz_out", i32), ("bits_out", i32), ("bits_in", i32), ("mask", i32), ("us", f32),
+    ]
 
 
 class FfnStage(C.Structure):
@@ -212,6 +220,8 @@ _SIGS = {
                              C.c_void_p]),
     "rr_abi_plan_struct_sizes": (None, [C.POINTER(C.c_size_t)] * 4),
     "rr_abi_ffn_chain_size": (C.c_size_t, []),
+    "rr_plan_timing_take": (i32, [C.POINTER(PlanTiming), i32]),
+    "rr_plan_timing_select": (i32, [i32, i32]),
     "rr_ffn_chain_f32": (i32, [C.POINTER(FfnChainArgs), c_stream]),
     "rr_reaction_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(Step)]),
     "rr_reaction_forward": (i32, [C.POINTER(Model), C.POINTER(Step), i32, c_stream]),

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "rr_common.h"
 
@@ -124,6 +125,7 @@ struct Ctx {
   bool use_side, use_aux, aux_bwd;
   bool train;                         // RR_PLAN_TRAIN: the forward packs the backward's transposed weights too
   bool ffn_chain;                     // the FFN head and its input-gradient chain as one launch each (rr_ffn_chain_f32)
+  bool timing;                        // RR_PLAN_TIME: events around the heavy launches
   hipStream_t cur;                    // stream of the backward chain being enqueued (main, or aux for the reactant pass)
   bool split;                         // encoder GEMMs on the bf16 matrix core (three exact bf16 terms per f32 operand)
   rr_pack_desc pq[RR_MAX_PACK];       // weight packs waiting for flush_packs()
@@ -186,9 +188,39 @@ void inplace_write(Ctx& c, const float* t) {
   }
 }
 
+// RR_PLAN_TIME: HIP events around the heavy launches of a plan call (rr_plan_timing_take reads them)
+struct TimingRec { hipEvent_t e0, e1; rr_plan_timing info; };
+std::vector<TimingRec> g_timing;
+std::mutex g_timing_mu;
+int g_timing_kinds = 7, g_timing_modes = 15;             // rr_plan_timing_select: which launches carry events
+
+struct Timed {                       // records e0 now, e1 at destruction - both on `st`
+  bool on;
+  hipStream_t st;
+  TimingRec r;
+  Timed(Ctx& c, hipStream_t st_, const rr_plan_timing& info, bool want = true);
+  ~Timed() {
+    if (!on) return;
+    if (hipEventRecord(r.e1, st) != hipSuccess) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); return; }
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    g_timing.push_back(r);
+  }
+};
+
 void flush_packs(Ctx& c, hipStream_t st) {
   if (c.npq > 0) RR_TRY(c, rr_pack_weights_f32(c.pq, c.npq, st));
   c.npq = 0;
+}
+
+Timed::Timed(Ctx& c, hipStream_t st_, const rr_plan_timing& info, bool want) : on(false), st(st_) {
+  if (!want || !c.timing || !c.launch || c.status != RR_OK) return;
+  if (!((g_timing_kinds >> info.kind) & 1) || (info.kind == 0 && !((g_timing_modes >> info.mode) & 1))) return;
+  r.info = info;
+  // (no system-scope fence with the markers: they only have to order and stamp - see stream_wait)
+  if (hipEventCreateWithFlags(&r.e0, hipEventDisableSystemFence) != hipSuccess) return;
+  if (hipEventCreateWithFlags(&r.e1, hipEventDisableSystemFence) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
+  if (hipEventRecord(r.e0, st) != hipSuccess) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); return; }
+  on = true;
 }
 
 // big = the GEMM runs over atoms / bonds (the FFN head runs over molecules: a few thousand rows, launch-bound either way)
@@ -238,6 +270,13 @@ void lin(Ctx& c, rr_linear_args& a, hipStream_t st) {
     a.c_amax_out = amax_claim(c, a.c);                  // what the next GEMM needs of this one's outputs
     if (a.dz_out) a.dz_amax_out = amax_claim(c, a.dz_out);
   }
+  rr_plan_timing ti;
+  memset(&ti, 0, sizeof(ti));
+  ti.kind = 0; ti.M = a.M; ti.N = a.N; ti.k1 = a.k1; ti.k2 = a.k2;
+  ti.mode = a.a_mask_bits ? 3 : (a.a_mask ? 2 : (a.a1_sub ? 1 : 0));
+  ti.residual = a.residual != nullptr; ti.c_pre = a.c_pre != nullptr; ti.dz_out = a.dz_out != nullptr;
+  ti.bits_out = a.mask_bits_out != nullptr; ti.bits_in = a.a_mask_bits != nullptr; ti.mask = a.a_mask != nullptr;
+  Timed t(c, st, ti, a.w_packed >= 2 && a.M >= 8192);      // (only the split GEMMs over atoms / bonds are timed)
   RR_TRY(c, rr_linear_f32(&a, st));
 }
 
@@ -252,6 +291,10 @@ void set_w(rr_linear_args& a, const Packed& p) {
 void gather_sum(Ctx& c, const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K, int H,
                 float* out, int64_t ld_out, hipStream_t st, const float* part = nullptr, int64_t n_part = 0, int64_t ld_part = 0,
                 bool claim = true) {
+  rr_plan_timing ti;
+  memset(&ti, 0, sizeof(ti));
+  ti.kind = 1; ti.M = n_out; ti.n_src = n_src; ti.N = H; ti.k1 = K;
+  Timed t(c, st, ti, n_out >= 8192);
   if (c.f16 && claim) RR_TRY(c, rr_gather_sum_amax_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, amax_claim(c, out), st));
   else if (part) RR_TRY(c, rr_gather_sum_padrow_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, st));
   else RR_TRY(c, rr_gather_sum_f32(src, n_src, ld_src, idx, n_out, K, H, out, ld_out, st));
@@ -270,6 +313,11 @@ void gather_epi(Ctx& c, const float* src, int64_t n_src, const int32_t* idx, int
   e.ld_add = H;
   for (int j = 0; j < n_adds; ++j) e.adds[j] = adds[j];
   e.amax_out = amax_claim(c, out);
+  rr_plan_timing ti;
+  memset(&ti, 0, sizeof(ti));
+  ti.kind = 2; ti.M = n_out; ti.n_src = n_src; ti.N = H; ti.k1 = K; ti.k2 = n_adds;
+  ti.mask = masked ? 1 : 0; ti.bits_in = (masked && y_bits != nullptr) ? 1 : 0;
+  Timed t(c, st, ti, n_out >= 8192);
   RR_TRY(c, rr_gather_sum_epi_f32(src, n_src, H, idx, n_out, K, H, part, n_part, r4(H), &e, out, H, st));
 }
 
@@ -1045,6 +1093,7 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
     c.ntr = c.namax = 0; c.amax_base = nullptr;
     c.train = (v & 1) != 0;
     c.ffn_chain = true;
+    c.timing = false;
     Plan P;
     memset(&P, 0, sizeof(P));
     forward_all(c, *model, *step, P);
@@ -1071,6 +1120,7 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
+  c.timing = (flags & RR_PLAN_TIME) != 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1110,6 +1160,7 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
+  c.timing = (flags & RR_PLAN_TIME) != 0;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1128,6 +1179,35 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   return c.ar.overflow ? RR_ERR_WORKSPACE : c.status;
 }
 
+int rr_plan_timing_select(int kinds, int modes) {
+  RR_CHECK_ARG(kinds >= 0 && kinds <= 7 && modes >= 0 && modes <= 15);
+  g_timing_kinds = kinds;
+  g_timing_modes = modes;
+  return RR_OK;
+}
+
+int rr_plan_timing_take(rr_plan_timing* out, int max_n) {
+  RR_CHECK_ARG(max_n >= 0 && (out || max_n == 0));
+  std::vector<TimingRec> recs;
+  {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    recs.swap(g_timing);
+  }
+  int n = 0, st = RR_OK;
+  for (TimingRec& r : recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) st = RR_ERR_LAUNCH;
+    if (st == RR_OK && n < max_n) {
+      out[n] = r.info;
+      out[n].us = ms * 1000.f;
+      ++n;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  return st == RR_OK ? n : st;
+}
+
 int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags, int which, int index,
                           const float** ptr, int64_t* rows, int64_t* ld) {
   int st = check(model, step);
@@ -1144,6 +1224,7 @@ int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags,
   c.aux_bwd = (flags & RR_PLAN_AUX_BACKWARD) != 0;
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
+  c.timing = (flags & RR_PLAN_TIME) != 0;
   c.s.main = c.s.side = c.s.aux = nullptr;
   c.cur = nullptr;
   Plan P;

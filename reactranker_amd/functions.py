@@ -973,6 +973,49 @@ class StepPlan:
     _ws_bytes = {}
     keep_last = False        # tests / embedding readers: remember the last step so saved() can look into its workspace
     last = None
+    timing = False           # RR_PLAN_TIME: HIP events around every split-GEMM / gather-sum launch inside the plans (bench.py)
+
+    @staticmethod
+    def select_timings(kinds: int = 7, modes: int = 15) -> None:
+        """which launches carry events while `timing` is on: bit k of kinds (0 split GEMM, 1 gather-sum, 2 gather-sum with
+        epilogue), bit m of modes (GEMM operand mode 0..3) - rr_plan_timing_select"""
+        check(lib().rr_plan_timing_select(int(kinds), int(modes)), "rr_plan_timing_select")
+
+    @staticmethod
+    def take_timings():
+        """Per-launch durations recorded by plan calls issued with `timing = True` (rr_plan_timing_take) as the records
+        bench.py aggregates: (kernel key, algorithmic flops, algorithmic bytes, seconds) - same keys and the same byte / flop
+        accounting as the per-op wrappers above (linear(), gather_sum())."""
+        buf = (_lib.PlanTiming * 4096)()
+        n = lib().rr_plan_timing_take(buf, 4096)
+        if n < 0:
+            check(n, "rr_plan_timing_take")
+        out = []
+        for r in buf[:n]:
+            if r.kind == 0:
+                M, N, kk = r.M, r.N, r.k1 + r.k2
+                two_src = r.mode == 1 or (r.mode == 2)
+                nbytes = 4 * (M * kk * (2 if two_src else 1) + N * kk + M * N * (1 + r.residual + r.c_pre))
+                bits_row = int(lib().rr_mask_bits_row_bytes(r.k1)) if r.bits_in else 0
+                nbytes += M * bits_row + (M * int(lib().rr_mask_bits_row_bytes(N)) if r.bits_out else 0)
+                if r.dz_out:
+                    nbytes += 4 * M * r.k1
+                nt = 4 if N <= 64 else (10 if N <= 160 else 19)
+                ntp = 38 if N > 304 else nt
+                if nt == 19 and ntp == 19 and M <= 8192:
+                    key = f"linear_split_kernel<19,5,{r.mode},8>"
+                else:
+                    key = f"linear_split_kernel<{ntp},{nt},{r.mode},{12 if nt == 19 else 8}>"
+                out.append((key, 2 * M * N * kk, nbytes, r.us * 1e-6))
+            else:
+                H, K = r.N, r.k1
+                nbytes = 4 * (r.n_src * H + r.M * H + r.M * K)
+                if r.kind == 2:
+                    nbytes += 4 * r.M * H * r.k2
+                    if r.mask:
+                        nbytes += r.M * int(lib().rr_mask_bits_row_bytes(H)) if r.bits_in else 4 * r.M * H
+                out.append(("gather_sum_epi_kernel" if r.kind == 2 else "gather_sum_kernel", 0, nbytes, r.us * 1e-6))
+        return out
 
     @staticmethod
     def saved(which: int, index: int = 0) -> Optional[torch.Tensor]:
@@ -1066,7 +1109,7 @@ class StepPlan:
                 (0 if SplitGemm.enabled else _lib.RR_PLAN_F32_GEMM) | (_lib.RR_PLAN_AUX_BACKWARD if AuxStream.backward else 0) |
                 (_lib.RR_PLAN_TRAIN if (train and not os.environ.get("RR_NO_TRAIN_PACK")) else 0) |
                 (_lib.RR_PLAN_F16X2_GEMM if (SplitGemm.enabled and SplitGemm.f16) else 0) |
-                (0 if FfnChain.enabled else _lib.RR_PLAN_NO_FFN_CHAIN))
+                (0 if FfnChain.enabled else _lib.RR_PLAN_NO_FFN_CHAIN) | (_lib.RR_PLAN_TIME if StepPlan.timing else 0))
 
 
 class ReactionModelFn(torch.autograd.Function):
