@@ -443,10 +443,11 @@ def compact_line(full: dict) -> dict:
     return line
 
 
-def emit(full: dict) -> str:
-    """Write the detail file(s), print the details to stderr and return the compact line as a string <= LINE_LIMIT bytes."""
-    paths = [os.path.join(REPO, "bench_detail.json")]
-    if os.path.isdir(os.path.join(REPO, "gpurun_out")):
+def emit(full: dict, write_detail: bool = True) -> str:
+    """Write the detail file(s), print the details to stderr and return the compact line as a string <= LINE_LIMIT bytes.
+    write_detail = False (--plan-only: a profiling target with nothing but the timed region) leaves an earlier detail file alone."""
+    paths = [os.path.join(REPO, "bench_detail.json")] if write_detail else []
+    if write_detail and os.path.isdir(os.path.join(REPO, "gpurun_out")):
         paths.append(os.path.join(REPO, "gpurun_out", "bench_detail.json"))
     written = []
     for q in paths:
@@ -948,7 +949,7 @@ def main():
         full.update(extra)
         if cpu:
             full["gpu_over_cpu"] = round(qps / cpu["value"], 1)
-        print(emit(full), flush=True)
+        print(emit(full, write_detail=not args.plan_only), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
