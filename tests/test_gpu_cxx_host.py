@@ -29,8 +29,8 @@ def _build():
 @pytest.mark.parametrize("arith", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("p,depth,ddepth", [(0.15, 3, 3), (0.0, 3, 3), (0.2, 1, 2)])
 def test_cxx_host_step_matches_the_python_modules(tmp_path, p, depth, ddepth, arith):
-    """both hosts issue the same step plans: in either GEMM arithmetic (the C++ host's default is the two-f16-term one,
-    RR_CXX_PLAN_FLAGS=0 selects three bf16 terms) the results must agree to the last bit of what the JSON carries"""
+    """both hosts issue the same step plans: in either GEMM arithmetic (the C++ host's default is three exact bf16 terms, plan flags 0;
+    RR_CXX_PLAN_FLAGS=32 selects the opt-in two-f16-term form) the results must agree to the last bit of what the JSON carries"""
     _build()
     from reactranker_amd import functions as Fn
     old_f16 = Fn.SplitGemm.f16
