@@ -4,7 +4,7 @@
 //
 // Reads one packed step from a shard file (layout: reactranker_amd/shards.py), uploads it with ONE copy, rebuilds the
 // feature arrays that do not travel (reactant rows = gathers of the distinct reactants' rows; f_bonds = f_atoms[b2a] ++
-// bond columns), then runs  rr_reaction_forward -> ListMLE (rr_listmle_fwd/bwd) -> rr_reaction_backward -> the gradient
+// bond columns), then runs  rr_reaction_forward -> ListMLE (rr_listmle_step_f32: loss + gradient in one launch) -> rr_reaction_backward -> the gradient
 // all-reduce of a data-parallel job (rr_allreduce_f32; one rank here)  and prints the loss and one checksum per gradient
 // tensor as JSON.  tests/test_gpu_cxx_host.py compares them with the Python modules
 // on the same weights, step and dropout stream.
@@ -173,12 +173,13 @@ int main(int argc, char** argv) {
   for (int64_t q = 0; q < Q; ++q) { seg[q + 1] = seg[q] + scope[q]; if (scope[q] > max_len) max_len = scope[q]; }
   int32_t* dseg = dmalloc<int32_t>(Q + 1);
   HIP_OK(hipMemcpyAsync(dseg, seg.data(), (Q + 1) * 4, hipMemcpyHostToDevice, st));
-  float *dloss = dmalloc<float>(1), *dpart = dmalloc<float>(Q), *dgl = dmalloc<float>(1), *dout = dmalloc<float>(M * task_num);
-  const float one = 1.0f;
-  HIP_OK(hipMemcpyAsync(dgl, &one, 4, hipMemcpyHostToDevice, st));
+  float *dloss = dmalloc<float>(1), *dpart = dmalloc<float>(Q), *dout = dmalloc<float>(M * task_num);
+  unsigned int* dticket = dmalloc<unsigned int>(1);      // the step kernel's ticket word: zeroed once, the kernel re-arms it
+  HIP_OK(hipMemsetAsync(dticket, 0, 4, st));
   HIP_OK(hipMemsetAsync(dout, 0, M * task_num * 4, st));
-  RR_OK_(rr_listmle_fwd_f32(out, task_num, F32("targets"), dseg, static_cast<int>(Q), max_len, dloss, dpart, st));
-  RR_OK_(rr_listmle_bwd_f32(out, task_num, F32("targets"), dseg, static_cast<int>(Q), max_len, dgl, dout, task_num, st));
+  // loss AND d loss / d score (the loss is the root of the graph: upstream gradient one) in ONE launch - the bits of
+  // rr_listmle_fwd_f32 + rr_listmle_bwd_f32 with *gloss = 1 (ABI revision 8)
+  RR_OK_(rr_listmle_step_f32(out, task_num, F32("targets"), dseg, static_cast<int>(Q), max_len, dloss, dpart, dticket, dout, task_num, st));
   rr_grads G; memset(&G, 0, sizeof(G));
   std::vector<std::pair<float*, size_t>> gbuf;
   const rr_linear_w* Ls[RR_G_FFN0 + RR_MAX_FFN] = {&m.enc_wi, &m.enc_wh, &m.enc_wo, &m.dif_wi, &m.dif_wh, &m.dif_wo};
