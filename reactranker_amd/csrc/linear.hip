@@ -739,7 +739,15 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   constexpr int BIAS_OFF = RS_EPI ? CS_OFF + WAVES * BN * 4 : 2 * PANEL;
   float* const bias_s = reinterpret_cast<float*>(smem + BIAS_OFF);
   constexpr int PF_OFF = BIAS_OFF + BN * 4;            // persistent form: 2 KiB per wave for the next block's step-0 operand chunks
-  const int t0 = blockIdx.y * NT;                      // first column tile of this workgroup
+  // Two column blocks (N > 304: <38, 19, ...>): a 1-D grid in which ids i and i + 8 are the two column blocks of ONE row block.
+  // Workgroup ids are dealt to the 8 XCDs round-robin, so the pair lands on one XCD within a few dispatches of each other and the
+  // second one finds the operand rows in that XCD's L2 (a (rows, 2) grid ran all first column blocks before any second one: every
+  // operand row left HBM twice).
+  constexpr bool PAIR = NTP == 2 * NT;
+  const unsigned int bx = PAIR ? (((blockIdx.x >> 4) << 3) + (blockIdx.x & 7u)) : blockIdx.x;
+  const unsigned int by = PAIR ? ((blockIdx.x >> 3) & 1u) : blockIdx.y;
+  if (PAIR && static_cast<int64_t>(bx) * (16 * WAVES) >= P.a.M) return;   // (uniform: the grid is padded to whole groups of 16 ids)
+  const int t0 = by * NT;                              // first column tile of this workgroup
   const int nth = NTP - t0 < NT ? NTP - t0 : NT;       // its column tiles (the last workgroup of a row block may have fewer)
   const bool full = nth == NT;
   const int n0 = t0 * 16;
@@ -761,11 +769,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   }
   RR_STAMP(0);
 #ifdef RR_TRACE
-  if (rr_trace_buf && threadIdx.x == 0 && blockIdx.y == 0) {
+  if (rr_trace_buf && threadIdx.x == 0 && by == 0) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    rr_trace_buf[static_cast<size_t>(blockIdx.x) * 8 + 4] = (static_cast<unsigned long long>(xcc) << 32) | hw;
+    rr_trace_buf[static_cast<size_t>(bx) * 8 + 4] = (static_cast<unsigned long long>(xcc) << 32) | hw;
   }
 #endif
 #ifdef RR_SPLIT_STAGGER
@@ -790,7 +798,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   // the workgroup's running maxima of |C| / |dz_out| (rr_linear_args.c_amax_out / dz_amax_out): two words behind everything else
   unsigned int* const amx = reinterpret_cast<unsigned int*>(smem + PF_OFF + (CAN_PERSIST ? WAVES * 2048 : 0));
   if (F16 && tid == 0) { amx[0] = 0u; amx[1] = 0u; }    // (the prologue's barrier orders this before any use)
-  int64_t g_cur = static_cast<int64_t>(blockIdx.x) * WAVES;            // first 16-row group of the current block
+  int64_t g_cur = static_cast<int64_t>(bx) * WAVES;                    // first 16-row group of the current block
   int64_t g_end = g_cur + WAVES;                                        // end of this workgroup's range
   if (persist) {
     const int64_t units = (a.M + 63) / 64, G = gridDim.x;
@@ -835,7 +843,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   }
   float dz_am = 0.f;                                   // largest |dz_out| this lane stored (rr_linear_args.dz_amax_out)
   float* dzrow = nullptr;                              // MODE 2 side output: dz_out (+)= masked operand
-  if ((MODE == 2 || MODE == 3) && a.dz_out && row_ok && blockIdx.y == 0) dzrow = a.dz_out + m * a.ld_dz;
+  if ((MODE == 2 || MODE == 3) && a.dz_out && row_ok && by == 0) dzrow = a.dz_out + m * a.ld_dz;
 
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
   const float* const wlane = a.w + t0 * (TERMS * 256) + lane * 4;   // this workgroup's tiles of a step; 16 B per lane inside a 1 KiB block
@@ -1338,7 +1346,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
       for (int d = lane; d < 160; d += 64) {
         const int r = d / 10, w = d - 10 * r;
         if (mw + r < a.M)
-          *reinterpret_cast<uint32_t*>(a.mask_bits_out + (mw + r) * rowb + blockIdx.y * 40 + 4 * w) = reinterpret_cast<const uint32_t*>(bits_s)[d];
+          *reinterpret_cast<uint32_t*>(a.mask_bits_out + (mw + r) * rowb + by * 40 + 4 * w) = reinterpret_cast<const uint32_t*>(bits_s)[d];
       }
     }
   }
@@ -1400,13 +1408,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
     }
   }
   if (!done && NT == 19 && mb_on && row_ok && (fkq & 1) == 0) {
-    uint32_t* d = reinterpret_cast<uint32_t*>(a.mask_bits_out + m * mask_bits_row(a.N) + blockIdx.y * 40 + (fkq >> 1) * 20);
+    uint32_t* d = reinterpret_cast<uint32_t*>(a.mask_bits_out + m * mask_bits_row(a.N) + by * 40 + (fkq >> 1) * 20);
 #pragma unroll
     for (int i = 0; i < 5; ++i) d[i] = mb[i];
   }
   // (the magnitude outputs exist in the two-f16-term instantiations only: the three-term kernels keep their registers)
   if (F16 && a.c_amax_out != nullptr) rr_amax_commit_wave(c_am, amx);
-  if (F16 && (MODE == 2 || MODE == 3) && a.dz_amax_out != nullptr && blockIdx.y == 0) {
+  if (F16 && (MODE == 2 || MODE == 3) && a.dz_amax_out != nullptr && by == 0) {
     rr_amax_commit_wave(dz_am, amx + 1);
     dz_am = 0.f;
   }
@@ -2529,7 +2537,9 @@ int launch_split_epi(const LinearParams& P, hipStream_t s) {
       return rr_launch_status();
     }
   }
-  const dim3 grid(static_cast<unsigned>(nblk), static_cast<unsigned>((NTP + NT - 1) / NT));
+  // (two column blocks: ids i, i + 8 of a 1-D grid are one row block's pair - see the kernel)
+  const dim3 grid = NTP == 2 * NT ? dim3(static_cast<unsigned>((nblk + 7) / 8 * 16), 1)
+                                  : dim3(static_cast<unsigned>(nblk), static_cast<unsigned>((NTP + NT - 1) / NT));
   linear_split_kernel<NTP, NT, MODE, WAVES, EPI, F16><<<grid, 64 * WAVES, smem, s>>>(P);
   return rr_launch_status();
 }
