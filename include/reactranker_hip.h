@@ -95,6 +95,18 @@ int rr_gather_sum_dropmask_f32(const float* src, int64_t n_src, int64_t ld_src, 
                                const int32_t* idx, int64_t n_out, int K, int H, float drop_p, uint64_t drop_seed,
                                float scale, float* out, int64_t ld_out, rr_stream_t stream);
 
+/* The sum over idx of a tensor that is itself a sum of n_srcs tensors of one shape (ABI revision 8):
+ *   out[r, :] = sum_{k<K, j = idx[r*K+k] >= 0} ( ((srcs[0][j, :] + srcs[1][j, :]) + srcs[2][j, :]) + ... )
+ * In the shared-prefix reactant backward a copy's d input is the sum of the dZ of every per-copy layer (models/mpn.py:94-97)
+ * and only its sum over the copies is needed: this replaces n_srcs - 1 rr_axpby_f32 passes over [n_src, H] plus a one-source
+ * gather by one pass that reads every addend once.  Same additions, same order: bit-identical to that sequence.
+ * 1 <= n_srcs <= RR_MAX_GATHER_SRCS; `srcs` is a HOST array of device pointers, all [n_src, ld_src].  H % 4 == 0 and 16-byte
+ * aligned rows (RR_ERR_ALIGN otherwise - callers then run the sequence above). */
+#define RR_MAX_GATHER_SRCS 4
+int rr_gather_sum_multi_f32(const float* const* srcs, int n_srcs, int64_t n_src, int64_t ld_src,
+                            const int32_t* idx, int64_t n_out, int K, int H,
+                            float* out, int64_t ld_out, rr_stream_t stream);
+
 /* Gather-sum with a fused epilogue - the form the backward chain uses (ABI revision 4):
  *   out[r, :] = M_r( sum_{k<K, idx[r*K+k] >= 0} src[idx[r*K+k], :] )  +  sum_{j<n_adds} adds[j][r, :]
  *   M_r(g)[c] = g[c]                                   without a mask

@@ -68,6 +68,7 @@ class WgradArgs(C.Structure):
 
 
 RR_MAX_GATHER_ADDS = 15
+RR_MAX_GATHER_SRCS = 4
 
 
 class GatherEpi(C.Structure):
@@ -171,6 +172,7 @@ _SIGS = {
     "rr_weighted_colsum_f32": (i32, [c_f32p, i64, i64, c_f32p, i32, c_f32p, i32, C.c_void_p, C.c_size_t, c_stream]),
     "rr_linear_f32": (i32, [C.POINTER(LinearArgs), c_stream]),
     "rr_linear_colsum_rows": (i64, [i64]),
+    "rr_gather_sum_multi_f32": (i32, [C.POINTER(C.c_void_p), i32, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, c_stream]),
     "rr_gather_sum_padrow_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, c_f32p, i64, c_stream]),
     "rr_gather_sum_amax_f32": (i32, [c_f32p, i64, i64, c_i32p, i64, i32, i32, c_f32p, i64, i64, c_f32p, i64, c_f32p, c_stream]),
     "rr_packed_weight_ld": (i64, [i32, i32]),

@@ -297,6 +297,50 @@ __global__ void __launch_bounds__(256) gather_sum_kernel(const float* __restrict
   amax_commit(am, amax_out);
 }
 
+// out[r] = sum_k (((s0[j_k] + s1[j_k]) + s2[j_k]) + s3[j_k]),  j_k = idx[r, k]: the sum over a distinct bond's copies of a
+// per-copy tensor that is itself a sum of NS per-copy tensors (the shared-prefix backward at depth >= 4: d input of a copy =
+// the dZ of every per-copy layer).  The inner sums used to be NS - 1 rr_axpby_f32 passes over [n_src, H] (two reads and a
+// write each) in front of a one-source gather; here every addend is read once and nothing of [n_src, H] is written.  Same
+// additions in the same order as that sequence - the result is bit-identical.
+struct GatherSrcs { const float* s[RR_MAX_GATHER_SRCS]; };
+template <int NS>
+__global__ void __launch_bounds__(256) gather_sum_multi_kernel(GatherSrcs S, int64_t ld_src, const int32_t* __restrict__ idx,
+                                                               int64_t n_out, int K, int HV, float* __restrict__ out,
+                                                               int64_t ld_out) {
+  const int64_t total = n_out * HV;
+  RR_GATHER_LOOP(e, static_cast<int>(gridDim.x), total) {
+    const int64_t r = e / HV;
+    const int c = static_cast<int>(e - r * HV) * 4;
+    const int32_t* ir = idx + r * K;
+    f32x4 acc = f32x4(0.0f);
+    int k = 0;
+    for (; k + 2 <= K; k += 2) {          // 2 * NS independent row loads in flight; pad entries read the zero chunk
+      const int32_t j0 = ir[k], j1 = ir[k + 1];
+      f32x4 v0[NS], v1[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        v0[q] = ld<4>(j0 >= 0 ? S.s[q] + j0 * ld_src + c : gather_zero);
+        v1[q] = ld<4>(j1 >= 0 ? S.s[q] + j1 * ld_src + c : gather_zero);
+      }
+      f32x4 t0 = v0[0], t1 = v1[0];
+#pragma unroll
+      for (int q = 1; q < NS; ++q) {
+        t0 = t0 + v0[q];
+        t1 = t1 + v1[q];
+      }
+      acc = (acc + t0) + t1;
+    }
+    for (; k < K; ++k) {
+      const int32_t j = ir[k];
+      f32x4 t = ld<4>(j >= 0 ? S.s[0] + j * ld_src + c : gather_zero);
+#pragma unroll
+      for (int q = 1; q < NS; ++q) t = t + ld<4>(j >= 0 ? S.s[q] + j * ld_src + c : gather_zero);
+      acc = acc + t;
+    }
+    st<4>(out + r * ld_out + c, acc);
+  }
+}
+
 // ------------------------------------------------------------------------ gather-sum with a fused epilogue
 // out[r] = mask_r (.) (sum_k src[idx[r,k]]) * scale  +  sum_j adds[j][r]
 // The backward chain never needs a gathered gradient as such: d message of one layer is consumed masked by the ReLU /
@@ -787,6 +831,31 @@ int rr_gather_sum_amax_f32(const float* src, int64_t n_src, int64_t ld_src, cons
 int rr_gather_sum_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,
                       int H, float* out, int64_t ld_out, rr_stream_t stream) {
   return rr_gather_sum_amax_f32(src, n_src, ld_src, idx, n_out, K, H, nullptr, 0, 0, out, ld_out, nullptr, stream);
+}
+
+int rr_gather_sum_multi_f32(const float* const* srcs, int n_srcs, int64_t n_src, int64_t ld_src, const int32_t* idx,
+                            int64_t n_out, int K, int H, float* out, int64_t ld_out, rr_stream_t stream) {
+  RR_CHECK_ARG(srcs && idx && out && n_srcs >= 1 && n_srcs <= RR_MAX_GATHER_SRCS && n_src >= 0 && n_out >= 0 && K >= 1 && H >= 1 &&
+               ld_src >= H && ld_out >= H);
+  GatherSrcs S{};
+  bool vec = (H % 4 == 0) && (ld_src % 4 == 0) && (ld_out % 4 == 0) && rr_aligned16(out);
+  for (int q = 0; q < n_srcs; ++q) {
+    RR_CHECK_ARG(srcs[q] != nullptr);
+    S.s[q] = srcs[q];
+    vec = vec && rr_aligned16(srcs[q]);
+  }
+  if (!vec) return RR_ERR_ALIGN;                        // (16-byte chunks only: callers fall back to rr_axpby_f32 + rr_gather_sum_f32)
+  if (n_out == 0) return RR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HV = H / 4;
+  const int grid = rr_grid_for(n_out * HV, 256);
+  switch (n_srcs) {
+    case 1: gather_sum_multi_kernel<1><<<grid, 256, 0, s>>>(S, ld_src, idx, n_out, K, HV, out, ld_out); break;
+    case 2: gather_sum_multi_kernel<2><<<grid, 256, 0, s>>>(S, ld_src, idx, n_out, K, HV, out, ld_out); break;
+    case 3: gather_sum_multi_kernel<3><<<grid, 256, 0, s>>>(S, ld_src, idx, n_out, K, HV, out, ld_out); break;
+    default: gather_sum_multi_kernel<4><<<grid, 256, 0, s>>>(S, ld_src, idx, n_out, K, HV, out, ld_out); break;
+  }
+  return rr_launch_status();
 }
 
 int rr_gather_sum_padrow_f32(const float* src, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out, int K,

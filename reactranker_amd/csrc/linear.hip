@@ -2672,7 +2672,6 @@ int rr_linear_f32(const rr_linear_args* args, rr_stream_t stream) {
   // Few rows (the FFN head: one row per molecule, 64 row blocks): cut the columns into 64-wide blocks as well, so the
   // launch covers the chip (5 x 64 workgroups at N = 300 instead of 64) - each element's k-order, hence its value, is
   // the same in every geometry.
-  if (a.N > 32 && a.M <= 8192 && fast && getenv("RR_FFN_NT2")) return launch_linear<2>(P, s, fast);   // experiment knob
   if (a.N <= 64 || a.M <= 8192) return launch_linear<4>(P, s, fast);
   if (a.N <= 160) return launch_linear<10>(P, s, fast);
   return launch_linear<19>(P, s, fast);

@@ -126,6 +126,7 @@ struct Ctx {
   bool train;                         // RR_PLAN_TRAIN: the forward packs the backward's transposed weights too
   bool ffn_chain;                     // the FFN head and its input-gradient chain as one launch each (rr_ffn_chain_f32)
   bool timing;                        // RR_PLAN_TIME: events around the heavy launches
+  bool gather_multi;                  // sums of per-copy tensors ride on the gather over the copies (rr_gather_sum_multi_f32)
   hipStream_t cur;                    // stream of the backward chain being enqueued (main, or aux for the reactant pass)
   bool split;                         // encoder GEMMs on the bf16 matrix core (three exact bf16 terms per f32 operand)
   rr_pack_desc pq[RR_MAX_PACK];       // weight packs waiting for flush_packs()
@@ -179,7 +180,9 @@ float* amax_claim(Ctx& c, const float* t) {
 // backward): a slot claimed before that write would bound only what the producer stored - the f16 scale leaves 2x-4x of
 // headroom, beyond it the split overflows to inf / NaN.  Such a tensor must reach its consumers WITHOUT a slot, so that
 // amax_of() runs its pass after the last write; a plan that violates this fails here instead of training on a stale bound.
-void inplace_write(Ctx& c, const float* t) {
+// (Since the shared-prefix tail forms d input in one gather epilogue no plan writes in place any more: the guard stays for
+// whoever adds such a kernel.)
+[[maybe_unused]] void inplace_write(Ctx& c, const float* t) {
   if (!c.f16 || t == nullptr || c.ar.base == nullptr) return;
   for (int i = 0; i < c.ntr; ++i) {
     if (c.tr[i].p != t || c.tr[i].amax == nullptr) continue;
@@ -298,6 +301,13 @@ void gather_sum(Ctx& c, const float* src, int64_t n_src, int64_t ld_src, const i
   if (c.f16 && claim) RR_TRY(c, rr_gather_sum_amax_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, amax_claim(c, out), st));
   else if (part) RR_TRY(c, rr_gather_sum_padrow_f32(src, n_src, ld_src, idx, n_out, K, H, part, n_part, ld_part, out, ld_out, st));
   else RR_TRY(c, rr_gather_sum_f32(src, n_src, ld_src, idx, n_out, K, H, out, ld_out, st));
+}
+
+// out[r] = sum over idx of (srcs[0] + srcs[1] + ...) (rr_gather_sum_multi_f32); `out` is modified in place afterwards, no slot
+void gather_multi(Ctx& c, const float* const* srcs, int n_srcs, int64_t n_src, int64_t ld_src, const int32_t* idx, int64_t n_out,
+                  int K, int H, float* out, int64_t ld_out, hipStream_t st) {
+  if (!c.launch) return;
+  RR_TRY(c, rr_gather_sum_multi_f32(srcs, n_srcs, n_src, ld_src, idx, n_out, K, H, out, ld_out, st));
 }
 
 // gather-sum whose epilogue applies the ReLU / dropout mask of the activation `y` (sign bits when a split GEMM wrote
@@ -746,8 +756,9 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     gather_epi(c, d_a, g.nA, g.b2t, g.nB, 1, H, d_msg, st, part, rr_linear_colsum_rows(g.nA), per_copy, S.msgs[depth - 1],
                S.bits[depth - 1], ks, nullptr, 0);
   }
-  float* d_inp_full = nullptr;
-  bool have_full = false;            // (flags, not pointer tests: a layout pass hands out null pointers)
+  const float* fulls[RR_MAX_GATHER_SRCS];   // the per-copy layers' dZ, oldest first (counted, not pointer-tested: a layout pass
+  int n_full = 0;                           // hands out null pointers)
+  const bool multi = H % 4 == 0 && c.gather_multi;
   int wh_started = accumulate;
   for (int it = depth - 2; it >= 1; --it) {                                             // per-copy W_h layers
     float* dz = d_msg;
@@ -762,13 +773,19 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x1_idx = g.b2a; w.x1_sub = S.msgs[it]; w.ldx1_sub = H; w.x1_sub_idx = g.b2revb;
     wgrad(c, w);
     wh_started = 1;
-    if (!have_full) {
-      d_inp_full = dz;
-      have_full = true;
+    // d input of a copy = the sum of these dZ; only its sum over the copies is needed (below).  Up to RR_MAX_GATHER_SRCS
+    // addends ride on that gather (rr_gather_sum_multi_f32); beyond that - or with rows that are not whole 16-byte chunks -
+    // the oldest ones are pre-summed by rr_axpby_f32 as before.  Either way the additions and their order are the same.
+    if (n_full < (multi ? RR_MAX_GATHER_SRCS : 1)) {
+      fulls[n_full++] = dz;
     } else {
       float* sum = c.alloc(g.nB, H);                                                     // fresh buffer (side-stream readers)
-      RR_TRY(c, rr_axpby_f32(1.0f, d_inp_full, 1.0f, dz, sum, g.nB * static_cast<int64_t>(H), st));
-      d_inp_full = sum;
+      RR_TRY(c, rr_axpby_f32(1.0f, fulls[0], 1.0f, multi ? fulls[1] : dz, sum, g.nB * static_cast<int64_t>(H), st));
+      fulls[0] = sum;
+      if (multi) {
+        for (int q = 1; q + 1 < n_full; ++q) fulls[q] = fulls[q + 1];
+        fulls[n_full - 1] = dz;
+      }
     }
     d_msg = c.alloc(g.nB, H);
     gather_epi(c, d_min, g.nB, g.b2b_t, g.nB, g.Kb, H, d_msg, st, partb, rr_linear_colsum_rows(g.nB), it - 1 >= 1, S.msgs[it],
@@ -790,16 +807,19 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     w.x1 = S.a0_u; w.ldx1 = H; w.k1 = H; w.x1_idx = gu.b2a; w.x1_sub = S.msg0_u; w.ldx1_sub = H; w.x1_sub_idx = gu.b2revb;
     wgrad(c, w);
   }
-  float* d_inp_u = c.alloc(gu.nB, H);
-  // d_inp_u is accumulated in place twice below (axpby, the ReLU backward of msg0): its bound for the W_i weight gradient is
-  // found by a pass AFTER the last write (amax_of in wgrad()), never by the gather that writes its first summand
-  if (have_full) {
-    gather_sum(c, d_inp_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, d_inp_u, H, st, nullptr, 0, 0, /*claim=*/false);
-    inplace_write(c, d_inp_u);
-    RR_TRY(c, rr_axpby_f32(1.0f, d_inp_u, 1.0f, dz1_u, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
-  } else {
-    RR_TRY(c, rr_axpby_f32(1.0f, dz1_u, 0.0f, nullptr, d_inp_u, gu.nB * static_cast<int64_t>(H), st));
+  // d input of the distinct bonds = sum over the copies of the per-copy layers' dZ  +  dz1_u  +  relu'(msg0_u) (.) d msg0_u.
+  // The first summand is a gather of its own (a different table); the other two ride on the epilogue of the gather that forms
+  // d msg0_u - addends in this order, the masked gather last: the additions of the former axpby / ReLU-backward passes over
+  // d_inp_u in their order, without those passes, and the tensor is written once (its bound comes out of that launch)
+  const float* adds[2];
+  int n_adds = 0;
+  if (n_full >= 1) {
+    float* over_copies = c.alloc(gu.nB, H);
+    if (n_full == 1) gather_sum(c, fulls[0], g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, over_copies, H, st, nullptr, 0, 0, /*claim=*/false);
+    else gather_multi(c, fulls, n_full, g.nB, H, bmap_t, gu.nB, bmap_t_cols, H, over_copies, H, st);
+    adds[n_adds++] = over_copies;
   }
+  adds[n_adds++] = dz1_u;
   float* d_min_u = c.alloc(gu.nB, H);
   float* part_u = c.alloc(rr_linear_colsum_rows(gu.nB), r4(H));
   {
@@ -809,9 +829,9 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     a.c = d_min_u; a.ldc = H;
     lin(c, a, st);
   }
-  float* d_msg0_u = bond_adjoint(c, gu, H, d_min_u, part_u, st);
-  inplace_write(c, d_inp_u);
-  RR_TRY(c, rr_relu_bwd_f32(d_msg0_u, S.msg0_u, 1.0f, nullptr, d_inp_u, gu.nB * static_cast<int64_t>(H), st));   // msg0 = relu(inp)
+  float* d_inp_u = c.alloc(gu.nB, H);
+  gather_epi(c, d_min_u, gu.nB, gu.b2b_t, gu.nB, gu.Kb, H, d_inp_u, st, part_u, rr_linear_colsum_rows(gu.nB), true, S.msg0_u, nullptr,
+             1.0f, adds, n_adds);                          // msg0 = relu(inp): no dropout, no sign-bit image
   rr_wgrad_args w = WA(gu.nB, H, d_inp_u, H, G.wi, m.enc_wi.in, G.bi, accumulate);
   w.x1 = gu.f_bonds; w.ldx1 = gu.ld_fb; w.k1 = m.bond_fdim;
   wgrad(c, w);
@@ -1094,6 +1114,7 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
     c.train = (v & 1) != 0;
     c.ffn_chain = true;
     c.timing = false;
+    c.gather_multi = false;             // (the layout with the pre-summed buffers: the larger one)
     Plan P;
     memset(&P, 0, sizeof(P));
     forward_all(c, *model, *step, P);
@@ -1121,6 +1142,7 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   c.timing = (flags & RR_PLAN_TIME) != 0;
+  c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1161,6 +1183,7 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   c.timing = (flags & RR_PLAN_TIME) != 0;
+  c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1225,6 +1248,7 @@ int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags,
   c.train = (flags & RR_PLAN_TRAIN) != 0;
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   c.timing = (flags & RR_PLAN_TIME) != 0;
+  c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
   c.s.main = c.s.side = c.s.aux = nullptr;
   c.cur = nullptr;
   Plan P;

@@ -163,6 +163,30 @@ def gather_sum_dropmask(src, y, scale: float, idx, H: int, p: float, seed: int, 
     return out
 
 
+MAX_GATHER_SRCS = _lib.RR_MAX_GATHER_SRCS
+
+
+def gather_sum_multi(srcs, idx, H: int, out=None):
+    """out[r] = sum_k (((srcs[0] + srcs[1]) + srcs[2]) + ...)[idx[r,k]] (rr_gather_sum_multi_f32): the chain of axpby passes
+    that would form the inner sum followed by gather_sum, bit-identical, with every addend read once and no [n_src, H]
+    intermediate.  More than MAX_GATHER_SRCS addends (or rows that are not whole 16-byte chunks): the oldest are pre-summed."""
+    srcs = list(srcs)
+    limit = MAX_GATHER_SRCS if (H % 4 == 0 and not os.environ.get("RR_NO_GATHER_MULTI")) else 1
+    while len(srcs) > limit:
+        srcs = [axpby(1.0, srcs[0], 1.0, srcs[1])] + srcs[2:]
+    if len(srcs) == 1:
+        return gather_sum(srcs[0], idx, H, out=out)
+    n_out, K = idx.shape
+    if out is None:
+        out = _new(srcs[0], n_out, H)
+    assert all(t.shape == srcs[0].shape and t.stride(0) == srcs[0].stride(0) for t in srcs)
+    arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+    with _Timed("gather_sum_multi_kernel", 0, 4 * (len(srcs) * srcs[0].shape[0] * H + n_out * H + n_out * K)):
+        check(lib().rr_gather_sum_multi_f32(arr, len(srcs), srcs[0].shape[0], _ld(srcs[0]), ptr(idx), n_out, K, H, ptr(out),
+                                            _ld(out), stream()), "rr_gather_sum_multi_f32")
+    return out
+
+
 def gather_sum_csr(src: torch.Tensor, offsets: torch.Tensor, idx: torch.Tensor, n_out: int, H: int) -> torch.Tensor:
     """out[r] = sum of src[idx[j]] for j in [offsets[r], offsets[r+1]) — adjoint of a gather through a generic index."""
     out = _new(src, n_out, H)
@@ -706,7 +730,7 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
     # reaches the shared prefix stays unmasked - gather_sum_masked masks it while summing over the copies
     per_copy = depth - 2 >= 1
     d_msg = gather_sum(d_a, g.b2t, H, row0_partial=part, mask=(msgs[depth - 1] if per_copy else None), mask_scale=ks)
-    d_inp_full = None
+    fulls = []                                                       # the per-copy layers' dZ: d input of a copy is their sum
     wh_started = acc0
     for it in reversed(range(1, depth - 1)):                         # per-copy W_h layers
         dz = d_msg
@@ -714,7 +738,7 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
         wgrad(nB, H, dz, gWh, dbias=gbh, x1=amsgs[it], k1=H, x1_idx=g.b2a, x1_sub=msgs[it], x1_sub_idx=g.b2revb,
               accumulate=wh_started, side=True)
         wh_started = True
-        d_inp_full = dz if d_inp_full is None else axpby(1.0, d_inp_full, 1.0, dz)   # fresh buffer (side-stream readers)
+        fulls.append(dz)
         d_msg = bond_message_adjoint(d_min, g, H, part, mask=(msgs[it] if it - 1 >= 1 else None), mask_scale=ks)
     # ---- shared prefix: msgs[1] = drop_copy(z1_u[bmap]),  z1_u = relu(inp_u + m_in0_u W_h^T + b_h)
     # (msgs[1] > 0) <=> kept and z1 > 0: mask and sum over the copies in one pass, the copies' masks re-derived from the
@@ -723,16 +747,13 @@ def mpn_backward_shared(gu, g, bmap_t, H: int, depth: int, Wi: LinW, Wh: LinW, W
         dz1_u = gather_sum_dropmask(d_msg, z1_u, ks, bmap_t, H, p, seed0)
     else:
         dz1_u = gather_sum_masked(d_msg, msgs[1], ks, bmap_t, H)
-    if d_inp_full is not None:
-        d_inp_u = gather_sum(d_inp_full, bmap_t, H)
-        axpby(1.0, d_inp_u, 1.0, dz1_u, out=d_inp_u)
-    else:
-        d_inp_u = dz1_u.clone()
+    # d input of the distinct bonds = (the per-copy layers' dZ summed over layers and copies) + dz1_u + relu'(msg0_u) * d msg0_u:
+    # the last two ride on the epilogue of the gather that forms d msg0_u (addends in this order, the masked gather last)
+    adds = ([gather_sum_multi(fulls, bmap_t, H)] if fulls else []) + [dz1_u]
     wgrad(nBu, H, dz1_u, gWh, dbias=gbh, x1=a0_u, k1=H, x1_idx=gu.b2a, x1_sub=msg0_u, x1_sub_idx=gu.b2revb,
           accumulate=wh_started, side=True)
     d_min_u, part_u = linear(nBu, H, Wh.pk_t(0, H), w_packed=True, a1=dz1_u, k1=H, colsum_w=gu.npad_b)
-    d_msg0_u = bond_message_adjoint(d_min_u, gu, H, part_u)
-    relu_bwd(d_msg0_u, msg0_u, 1.0, acc=d_inp_u, want_dz=False)       # msg0 = relu(inp)
+    d_inp_u = bond_message_adjoint(d_min_u, gu, H, part_u, mask=msg0_u, mask_scale=1.0, adds=adds)   # msg0 = relu(inp)
     wgrad(nBu, H, d_inp_u, gWi, dbias=gbi, x1=gu.f_bonds, k1=FBOND, accumulate=acc0, side=True)
     return gWi, gbi, gWh, gbh, gWo, gbo
 

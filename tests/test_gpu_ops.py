@@ -1,6 +1,9 @@
 """GPU parity of the individual HIP ops (called through the C-ABI) against plain fp32 math on the
 CPU.  Tolerance for floating point: |got - ref| <= 1e-5 * (1 + |ref|) (north star: 1e-5 fp32);
 index / mask results are bit-exact."""
+import ctypes as C
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -332,6 +335,45 @@ def test_gather_sum_masked_equals_relu_backward_then_gather(H, K):
     assert torch.equal(got, ref)
     want = np.where(idx[..., None] >= 0, np.where(mask.cpu().numpy() > 0, src.cpu().numpy() * np.float32(1.0 / 0.9), 0)[np.maximum(idx, 0)], 0).sum(1)
     close(got, want, what="masked gather")
+
+
+@pytest.mark.parametrize("H", [300, 600, 30])
+@pytest.mark.parametrize("K", [1, 2, 5, 12, 64])
+@pytest.mark.parametrize("n_srcs", [1, 2, 3, 4, 6])
+def test_gather_sum_of_a_sum_equals_the_axpby_chain_then_gather(H, K, n_srcs):
+    """rr_gather_sum_multi_f32 (shared-prefix backward at depth >= 4: the per-copy layers' dZ summed over the layers and over
+    the copies in one pass) against the sequence it replaces - rr_axpby_f32 passes forming the inner sum, then rr_gather_sum_f32:
+    torch.equal.  More than RR_MAX_GATHER_SRCS addends, and H = 30 (rows that are not 16-byte chunks), take the pre-summed route."""
+    rng = np.random.default_rng(1000 * H + 10 * K + n_srcs)
+    n_src, n_out = 1543, 97
+    srcs = [dev((rng.standard_normal((n_src, H)) * 0.05).astype(np.float32)) for _ in range(n_srcs)]
+    idx = rng.integers(-1, n_src, size=(n_out, K)).astype(np.int32)
+    idx[0] = -1
+    inner = srcs[0]
+    for t in srcs[1:]:
+        inner = Fn.axpby(1.0, inner, 1.0, t)
+    ref = Fn.gather_sum(inner, dev(idx), H)
+    got = Fn.gather_sum_multi(srcs, dev(idx), H)
+    assert torch.equal(got, ref)
+    assert float(got[0].abs().max()) == 0.0
+    os.environ["RR_NO_GATHER_MULTI"] = "1"
+    try:
+        assert torch.equal(Fn.gather_sum_multi(srcs, dev(idx), H), ref)
+    finally:
+        del os.environ["RR_NO_GATHER_MULTI"]
+    want = sum(np.where(idx[..., None] >= 0, t.cpu().numpy().astype(np.float64)[np.maximum(idx, 0)], 0).sum(1) for t in srcs)
+    close(got, want, what="gather of a sum")
+
+
+def test_gather_sum_multi_rejects_bad_arguments():
+    src = dev(np.zeros((8, 30), np.float32))
+    idx = dev(np.zeros((4, 2), np.int32))
+    out = torch.empty(4, 30, device="cuda")
+    arr = (C.c_void_p * 5)(*([src.data_ptr()] * 5))
+    L = _lib.lib()
+    assert L.rr_gather_sum_multi_f32(arr, 2, 8, 30, Fn.ptr(idx), 4, 2, 30, Fn.ptr(out), 30, None) == -2      # RR_ERR_ALIGN
+    assert L.rr_gather_sum_multi_f32(arr, 5, 8, 32, Fn.ptr(idx), 4, 2, 32, Fn.ptr(out), 32, None) == -1
+    assert L.rr_gather_sum_multi_f32(arr, 0, 8, 32, Fn.ptr(idx), 4, 2, 32, Fn.ptr(out), 32, None) == -1
 
 
 @pytest.mark.parametrize("H,p", [(300, 0.1), (300, 0.0), (64, 0.35), (600, 0.2)])

@@ -77,6 +77,22 @@ def test_plan_is_bit_identical_to_the_per_op_path(H, d, dd, fd, bias, tn, last, 
         assert not torch.equal(b[0], c[0])
 
 
+@pytest.mark.parametrize("d", [4, 6, 8])
+def test_plan_sum_of_the_per_copy_gradients_on_the_gather_equals_the_pre_summed_form(d, monkeypatch):
+    """Shared-prefix backward at depth >= 4: the per-copy layers' dZ ride on the gather over the copies
+    (rr_gather_sum_multi_f32); RR_NO_GATHER_MULTI=1 pre-sums them with rr_axpby_f32 as before.  Same additions, same order."""
+    cfg = dict(hidden_size=64, mpnn_depth=d, mpnn_diff_depth=2, ffn_depth=2, use_bias=True, task_num=1,
+               ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
+    w = synth.seeded_weights(O.model_shapes(64, d, 2, 2, 1, 1, True), 5)
+    model = make_model(cfg, w, dropout=0.1).train()
+    qb = synth.make_queries(11, 3, [6, 4, 8], atoms_lo=5, atoms_hi=12)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    a = _run(model, rb, pb, qb, 7, plan=True)
+    monkeypatch.setenv("RR_NO_GATHER_MULTI", "1")
+    _same(a, _run(model, rb, pb, qb, 7, plan=True))
+    _same(a, _run(model, rb, pb, qb, 7, plan=False))
+
+
 def test_plan_without_side_and_aux_streams_and_no_grad_forward():
     cfg = dict(hidden_size=64, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
                ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
