@@ -127,6 +127,8 @@ struct Ctx {
   bool ffn_chain;                     // the FFN head and its input-gradient chain as one launch each (rr_ffn_chain_f32)
   bool timing;                        // RR_PLAN_TIME: events around the heavy launches
   bool gather_multi;                  // sums of per-copy tensors ride on the gather over the copies (rr_gather_sum_multi_f32)
+  bool tail_pass;                     // the encoder pass being enqueued is the last one of the backward call (see wgrad)
+  bool side_joined;                   // the chain has waited for the side stream and nothing was put there since
   hipStream_t cur;                    // stream of the backward chain being enqueued (main, or aux for the reactant pass)
   bool split;                         // encoder GEMMs on the bf16 matrix core (three exact bf16 terms per f32 operand)
   rr_pack_desc pq[RR_MAX_PACK];       // weight packs waiting for flush_packs()
@@ -332,7 +334,7 @@ void gather_epi(Ctx& c, const float* src, int64_t n_src, const int32_t* idx, int
 }
 
 // weight gradient on the side stream: waits for the main stream's work so far (its operands), returns immediately
-void wgrad(Ctx& c, rr_wgrad_args& a) {
+void wgrad(Ctx& c, rr_wgrad_args& a, bool tail = false) {
   const size_t wb = rr_linear_wgrad_workspace_bytes(a.M, a.N, a.k1 + a.k2);
   a.workspace = c.alloc(1, static_cast<int64_t>((wb + 3) / 4));
   a.workspace_bytes = wb;
@@ -344,8 +346,18 @@ void wgrad(Ctx& c, rr_wgrad_args& a) {
     if (a.k2 > 0) a.x2_amax = amax_of(c, a.x2, c.cur);
   }
   if (!c.launch || c.status != RR_OK) return;
-  hipStream_t st = c.use_side ? c.s.side : c.cur;
-  if (c.use_side) c.fail(stream_wait(c.s.side, c.cur));
+  // tail: the last weight gradient of a backward call - nothing is left on the chain for it to overlap with, the optimizer waits
+  // for it.  It runs ON the chain, behind everything the side stream holds (same order of accumulation into dw), instead of one
+  // stream hop to the side stream and one back (~11 us each against ~5 us between two kernels of one stream).
+  const bool join = tail && c.use_side && c.tail_pass && c.cur == c.s.main && !getenv("RR_NO_TAIL_JOIN");
+  hipStream_t st = (c.use_side && !join) ? c.s.side : c.cur;
+  if (join) {
+    c.fail(stream_wait(c.cur, c.s.side));
+    c.side_joined = true;
+  } else if (c.use_side) {
+    c.fail(stream_wait(c.s.side, c.cur));
+    c.side_joined = false;
+  }
   c.fail(rr_linear_wgrad_f32(&a, st));
   if (c.status != RR_OK && getenv("RR_PLAN_DEBUG"))
     fprintf(stderr, "[rr plan] wgrad status %d: M %lld N %d k1 %d k2 %d ws %zu\n", c.status, (long long)a.M, a.N, a.k1, a.k2, wb);
@@ -723,7 +735,7 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
   float* d_inp = cur;
   rr_wgrad_args w = WA(g.nB, H, d_inp, H, G.wi, m.enc_wi.in, G.bi, accumulate);
   w.x1 = g.f_bonds; w.ldx1 = g.ld_fb; w.k1 = m.bond_fdim;
-  wgrad(c, w);
+  wgrad(c, w, /*tail=*/true);
 }
 
 void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr_graph& g, const int32_t* bmap_t, int bmap_t_cols,
@@ -834,7 +846,7 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
              1.0f, adds, n_adds);                          // msg0 = relu(inp): no dropout, no sign-bit image
   rr_wgrad_args w = WA(gu.nB, H, d_inp_u, H, G.wi, m.enc_wi.in, G.bi, accumulate);
   w.x1 = gu.f_bonds; w.ldx1 = gu.ld_fb; w.k1 = m.bond_fdim;
-  wgrad(c, w);
+  wgrad(c, w, /*tail=*/true);
 }
 
 // adjoint of mpndiff_forward -> d_x [nA, H]
@@ -1048,11 +1060,13 @@ void backward_all(Ctx& c, const rr_model& m, const rr_step& s, Plan& P, const fl
   if (c.launch && fork) c.fail(stream_wait(c.s.aux, main));
   mpn_backward(c, m, s.p, P.pk, wh_t, wo_t, p, P.p, d_diff, 1.0f, E, 0);
   if (fork) c.cur = c.s.aux;
+  c.tail_pass = !fork;
   if (s.mode == RR_STEP_PREFIX) mpn_backward_shared(c, m, s.u, s.r, s.bmap_t, s.bmap_t_cols, wh_t, wo_t, p, P.r, d_r, -1.0f, E, 1);
   else mpn_backward(c, m, s.r, P.pk, wh_t, wo_t, p, P.r, d_r, -1.0f, E, 1);
   c.cur = main;
+  c.tail_pass = false;
   if (c.launch && fork) c.fail(stream_wait(main, c.s.aux));
-  if (c.launch && c.use_side) c.fail(stream_wait(main, c.s.side));     // weight gradients are complete from here on
+  if (c.launch && c.use_side && !c.side_joined) c.fail(stream_wait(main, c.s.side));     // weight gradients are complete from here on
 }
 
 int check_graph(const rr_graph& g, int need_fb_sum, int need_f_bonds) {
@@ -1115,6 +1129,7 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
     c.ffn_chain = true;
     c.timing = false;
     c.gather_multi = false;             // (the layout with the pre-summed buffers: the larger one)
+    c.tail_pass = c.side_joined = false;
     Plan P;
     memset(&P, 0, sizeof(P));
     forward_all(c, *model, *step, P);
@@ -1143,6 +1158,7 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   c.timing = (flags & RR_PLAN_TIME) != 0;
   c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
+  c.tail_pass = c.side_joined = false;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1184,6 +1200,7 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   c.timing = (flags & RR_PLAN_TIME) != 0;
   c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
+  c.tail_pass = c.side_joined = false;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1249,6 +1266,7 @@ int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags,
   c.ffn_chain = (flags & RR_PLAN_NO_FFN_CHAIN) == 0 && !getenv("RR_NO_FFN_CHAIN");
   c.timing = (flags & RR_PLAN_TIME) != 0;
   c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
+  c.tail_pass = c.side_joined = false;
   c.s.main = c.s.side = c.s.aux = nullptr;
   c.cur = nullptr;
   Plan P;
