@@ -446,7 +446,6 @@ __global__ void __launch_bounds__(THREADS, 3) linear_fast_kernel(const LinearPar
         *reinterpret_cast<f32x4*>(dzrow + kl) = a.dz_accumulate ? v + rc : v;
     }
     float* As = lds[buf];
-    float* Bs = lds[buf] + BM * BK;
     *reinterpret_cast<f32x4*>(As + srow * BK + 4 * swz(srow, skq)) = v;
   };
 
@@ -727,7 +726,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) linear_split_k
   constexpr int TERMS = F16 ? 2 : 3;                   // operand terms: three bf16 or two f16
   constexpr int PANEL = NT * TERMS * 1024;             // bytes of one k-step's weight image in LDS
   constexpr int SRC_PANEL = NTP * TERMS * 1024;            // ... and in the packed weights
-  constexpr int S_BM = 16 * WAVES, S_THREADS = 64 * WAVES;
+  constexpr int S_THREADS = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS layout.  k-loop: two weight images [0, 2 * PANEL).  Epilogue of the 12-wave geometry (RS_EPI): the images' space
   // becomes twelve wave-private transposition regions of 8 rows x 77 float4 (the 77th is padding: rows 1232 bytes apart
