@@ -7,11 +7,11 @@ while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   d=../../build/variants/$name
   mkdir -p $d
-  for f in gather elementwise loss linear plan; do
+  for f in gather elementwise loss linear ffn plan; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $flags -c $f.hip -o $d/$f.o 2>/dev/null &
   done
   wait
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $d/gather.o $d/elementwise.o $d/loss.o pack.o $d/linear.o $d/plan.o collective.o -ldl -o ../../build/variants/lib_$name.so
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $d/gather.o $d/elementwise.o $d/loss.o pack.o $d/linear.o $d/ffn.o $d/plan.o collective.o -ldl -o ../../build/variants/lib_$name.so
   rm -rf $d
   echo built $name
 done
