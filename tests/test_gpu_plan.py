@@ -93,6 +93,23 @@ def test_plan_sum_of_the_per_copy_gradients_on_the_gather_equals_the_pre_summed_
     _same(a, _run(model, rb, pb, qb, 7, plan=False))
 
 
+@pytest.mark.parametrize("p,dedup", [(0.1, "auto"), (0.0, False)])
+def test_plan_last_weight_gradient_on_the_chain_equals_the_side_stream_placement(p, dedup, monkeypatch):
+    """The last weight gradient of rr_reaction_backward runs on the caller's stream behind the side stream's work (round 5);
+    RR_NO_TAIL_JOIN=1 puts it back on the side stream.  Same kernels, same order of accumulation: every gradient bit for bit
+    (shared-prefix reactant pass with dropout, and the plain two-pass form)."""
+    cfg = dict(hidden_size=64, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
+               ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
+    w = synth.seeded_weights(O.model_shapes(64, 3, 3, 3, 1, 1, True), 5)
+    model = make_model(cfg, w, dropout=p).train()
+    model.dedup_reactants = dedup
+    qb = synth.make_queries(13, 3, [6, 4, 8], atoms_lo=5, atoms_hi=12)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    a = _run(model, rb, pb, qb, 7, plan=True)
+    monkeypatch.setenv("RR_NO_TAIL_JOIN", "1")
+    _same(a, _run(model, rb, pb, qb, 7, plan=True))
+
+
 def test_plan_without_side_and_aux_streams_and_no_grad_forward():
     cfg = dict(hidden_size=64, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
                ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
