@@ -187,9 +187,23 @@ class Runner:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def settle(self, batches, limit=40):
+        from reactranker_amd import functions as Fn
+        """Untimed steps until the library has finished MEASURING which order of weight gradient and input-gradient GEMM this
+        workload prefers (functions.WgradOrder: ~14 backward calls per workload, the two orders alternated; the results of a
+        step are the same bits in either) - a timed region starts in the steady state the rest of a training run sees."""
+        n = 0
+        while n < limit and not Fn.WgradOrder.settled():
+            self.train_step(batches(n))
+            n += 1
+            if n % 4 == 0:
+                self.fence()                              # (let the events of the last calls complete)
+        self.order_tuning_steps = getattr(self, "order_tuning_steps", 0) + n
+
     def timed(self, batches, n_steps):
         """EXACTLY n_steps optimizer steps between two fences; returns (seconds, per-step device ms list, last loss)."""
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+        self.settle(batches)
         self.fence()
         # The host keeps ~50 k molecule descriptions (Python objects) per step pool: a generation-2 collection that walks them
         # takes tens of milliseconds and lands in whichever step allocates the object that triggers it (seen as ONE 40 ms step in
@@ -957,6 +971,10 @@ def main():
             "f32_mfma_path": f32_path, other_key: other_path, "epoch_stream": epoch, "presets": presets or None, "dp": dp_info,
             "kernels": ktable, "kernels_isolated": ktable_iso, "final_loss": round(loss_val, 6),
             "host_prep_s": {"synthetic_generation": round(R.t_gen, 2), "native_pack_and_upload": round(R.t_pack, 2)},
+            "wgrad_order": {"mode": Fn.WgradOrder.mode, "untimed_tuning_steps": getattr(R, "order_tuning_steps", 0),
+                            "early_by_workload": Fn.WgradOrder.choices(),
+                            "note": "order of a layer's weight gradient and input-gradient GEMM, measured per workload in untimed steps "
+                                    "before each timed region (functions.WgradOrder); results are the same bits in either order"},
         }
         full.update(extra)
         if cpu:

@@ -643,9 +643,15 @@ enum { RR_PLAN_NO_SIDE_STREAM = 1, RR_PLAN_NO_AUX_STREAM = 2,
                                         in the workspace).  Ignored with RR_PLAN_F32_GEMM; layout-changing (ABI revision 7). */
        RR_PLAN_NO_FFN_CHAIN = 64,    /* the FFN head's layers as separate launches instead of rr_ffn_chain_f32 (same results
                                         bit for bit, same workspace layout: an A/B knob; ABI revision 8) */
-       RR_PLAN_TIME = 128 };         /* measurement: HIP events on the launch stream around every split-GEMM and gather-sum launch
+       RR_PLAN_TIME = 128,           /* measurement: HIP events on the launch stream around every split-GEMM and gather-sum launch
                                         of this call, collected by rr_plan_timing_take (costs ~5 us of stream time per launch:
                                         not for timed runs; ABI revision 8) */
+       RR_PLAN_WGRAD_EARLY = 256 };  /* rr_reaction_backward only: the W_h weight gradient of a message-passing layer is issued in
+                                        front of that layer's input-gradient GEMM instead of behind it (both read the same dZ).
+                                        Same kernels, same order on the weight-gradient stream, same workspace layout, same bits;
+                                        which order is faster depends on the workload (-1.3 % ... +2.4 % on the step over the four
+                                        BASELINE configurations, profiles/r05_experiments.txt item 19): a host may time both and
+                                        keep the better one, as reactranker_amd.functions.WgradOrder does (ABI revision 8) */
 
 typedef struct rr_step {
   rr_graph p, r, u;

@@ -85,6 +85,7 @@ RR_STEP_PLAIN, RR_STEP_DEDUP, RR_STEP_PREFIX = 0, 1, 2
 RR_PLAN_NO_SIDE_STREAM, RR_PLAN_NO_AUX_STREAM, RR_PLAN_F32_GEMM, RR_PLAN_AUX_BACKWARD, RR_PLAN_TRAIN, RR_PLAN_F16X2_GEMM = 1, 2, 4, 8, 16, 32
 RR_PLAN_NO_FFN_CHAIN = 64
 RR_PLAN_TIME = 128
+RR_PLAN_WGRAD_EARLY = 256
 
 
 class PlanTiming(C.Structure):

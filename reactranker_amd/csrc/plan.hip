@@ -127,6 +127,7 @@ struct Ctx {
   bool ffn_chain;                     // the FFN head and its input-gradient chain as one launch each (rr_ffn_chain_f32)
   bool timing;                        // RR_PLAN_TIME: events around the heavy launches
   bool gather_multi;                  // sums of per-copy tensors ride on the gather over the copies (rr_gather_sum_multi_f32)
+  bool wgrad_early;                   // RR_PLAN_WGRAD_EARLY: W_h weight gradients issued in front of the dX GEMM of their layer
   bool tail_pass;                     // the encoder pass being enqueued is the last one of the backward call (see wgrad)
   bool side_joined;                   // the chain has waited for the side stream and nothing was put there since
   hipStream_t cur;                    // stream of the backward chain being enqueued (main, or aux for the reactant pass)
@@ -721,10 +722,11 @@ void mpn_backward(Ctx& c, const rr_model& m, const rr_graph& g, const PackedW& p
     a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
     a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
     a.c = d_min; a.ldc = H;
-    lin(c, a, st);
     rr_wgrad_args w = WA(g.nB, H, dz, H, G.wh, H, G.bh, (accumulate || it != depth - 2) ? 1 : 0);
     w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x1_idx = g.b2a; w.x1_sub = S.msgs[it]; w.ldx1_sub = H; w.x1_sub_idx = g.b2revb;
-    wgrad(c, w);
+    if (c.wgrad_early) wgrad(c, w);                      // (starts with the dX GEMM that reads the same dZ instead of behind it)
+    lin(c, a, st);
+    if (!c.wgrad_early) wgrad(c, w);
     dzs[ndz++] = dz;
     // adjoint of the bond message (one gather over b2b_t; row 0 from the GEMM's weighted column sums), masked by msgs[it];
     // the last one (it == 0: msgs[0] = relu(input), no dropout) adds the dZ of every iteration -> d input
@@ -780,10 +782,11 @@ void mpn_backward_shared(Ctx& c, const rr_model& m, const rr_graph& gu, const rr
     a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
     a.colsum_w = g.npad_b; a.colsum_partial = partb; a.ld_partial = r4(H);
     a.c = d_min; a.ldc = H;
-    lin(c, a, st);
     rr_wgrad_args w = WA(g.nB, H, dz, H, G.wh, H, G.bh, wh_started);
     w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x1_idx = g.b2a; w.x1_sub = S.msgs[it]; w.ldx1_sub = H; w.x1_sub_idx = g.b2revb;
-    wgrad(c, w);
+    if (c.wgrad_early) wgrad(c, w);
+    lin(c, a, st);
+    if (!c.wgrad_early) wgrad(c, w);
     wh_started = 1;
     // d input of a copy = the sum of these dZ; only its sum over the copies is needed (below).  Up to RR_MAX_GATHER_SRCS
     // addends ride on that gather (rr_gather_sum_multi_f32); beyond that - or with rows that are not whole 16-byte chunks -
@@ -904,10 +907,11 @@ float* mpndiff_backward(Ctx& c, const rr_model& m, const rr_graph& g, float p, c
       a.a1 = dz; a.lda1 = H; a.k1 = H; set_w(a, wh_t);
       a.colsum_w = g.npad; a.colsum_partial = part2; a.ld_partial = r4(H);
       a.c = d_a2; a.ldc = H;
-      lin(c, a, st);
       rr_wgrad_args w = WA(g.nA, H, dz, H, G.w[RR_G_DIF_WH], H + FB, G.b[RR_G_DIF_WH], it != depth - 2 ? 1 : 0);
       w.x1 = S.amsgs[it]; w.ldx1 = H; w.k1 = H; w.x2 = g.fb_sum; w.ldx2 = g.ld_fbs; w.k2 = FB;
-      wgrad(c, w);
+      if (c.wgrad_early) wgrad(c, w);
+      lin(c, a, st);
+      if (!c.wgrad_early) wgrad(c, w);
       dzs[ndz++] = dz;
       cur = c.alloc(g.nA, H);
       gather_epi(c, d_a2, g.nA, g.a2a_t, g.nA, g.K, H, cur, st, part2, rr_linear_colsum_rows(g.nA), true, S.msgs[it], S.bits[it],
@@ -1130,6 +1134,7 @@ size_t rr_reaction_workspace_bytes(const rr_model* model, const rr_step* step) {
     c.timing = false;
     c.gather_multi = false;             // (the layout with the pre-summed buffers: the larger one)
     c.tail_pass = c.side_joined = false;
+    c.wgrad_early = false;
     Plan P;
     memset(&P, 0, sizeof(P));
     forward_all(c, *model, *step, P);
@@ -1159,6 +1164,7 @@ int rr_reaction_forward(const rr_model* model, const rr_step* step, int flags, r
   c.timing = (flags & RR_PLAN_TIME) != 0;
   c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
   c.tail_pass = c.side_joined = false;
+  c.wgrad_early = (flags & RR_PLAN_WGRAD_EARLY) != 0 || getenv("RR_WGRAD_EARLY") != nullptr;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1201,6 +1207,7 @@ int rr_reaction_backward(const rr_model* model, const rr_step* step, const float
   c.timing = (flags & RR_PLAN_TIME) != 0;
   c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
   c.tail_pass = c.side_joined = false;
+  c.wgrad_early = (flags & RR_PLAN_WGRAD_EARLY) != 0 || getenv("RR_WGRAD_EARLY") != nullptr;
   st = get_streams(static_cast<hipStream_t>(stream), &c.s);
   if (st != RR_OK) return st;
   c.cur = c.s.main;
@@ -1267,6 +1274,7 @@ int rr_reaction_saved_f32(const rr_model* model, const rr_step* step, int flags,
   c.timing = (flags & RR_PLAN_TIME) != 0;
   c.gather_multi = !getenv("RR_NO_GATHER_MULTI");
   c.tail_pass = c.side_joined = false;
+  c.wgrad_early = (flags & RR_PLAN_WGRAD_EARLY) != 0 || getenv("RR_WGRAD_EARLY") != nullptr;
   c.s.main = c.s.side = c.s.aux = nullptr;
   c.cur = nullptr;
   Plan P;

@@ -1133,6 +1133,88 @@ class StepPlan:
                 (0 if FfnChain.enabled else _lib.RR_PLAN_NO_FFN_CHAIN) | (_lib.RR_PLAN_TIME if StepPlan.timing else 0))
 
 
+class WgradOrder:
+    """Which order of a message-passing layer's W_h weight gradient and input-gradient GEMM the backward plan uses
+    (RR_PLAN_WGRAD_EARLY).  Both orders run the same kernels on the same values - every gradient is the same bits - but they
+    interleave the weight-gradient stream with the main chain differently, and which one is faster depends on the workload:
+    over the four BASELINE configurations the step moves by -1.3 % ... +2.4 % (profiles/r05_experiments.txt item 19).  So the
+    choice is MEASURED: for the first calls of a workload (hidden size, depths, reactant mode, product bonds in units of 16k)
+    the backward alternates the two orders with HIP events around the plan call, and keeps "early" only if its median is
+    clearly below "late"'s.  mode: "auto" (default), "late", "early" (RR_WGRAD_ORDER).  Nothing here synchronises: finished
+    events are read with query() on a later call."""
+    mode = os.environ.get("RR_WGRAD_ORDER", "auto")
+    warm = 2                 # calls of a workload before the first sample
+    samples = 6              # per order
+    margin = 0.004           # "early" must win by this fraction of the median
+    _state = {}
+
+    @classmethod
+    def reset(cls):
+        cls._state = {}
+
+    @classmethod
+    def _get(cls, sig):
+        st = cls._state.get(sig)
+        if st is None:
+            st = cls._state[sig] = dict(calls=0, choice=None, times={False: [], True: []}, pending=[])
+        return st
+
+    @classmethod
+    def _harvest(cls, st):
+        keep = []
+        for early, e0, e1 in st["pending"]:
+            if e1.query():
+                st["times"][early].append(e0.elapsed_time(e1))
+            else:
+                keep.append((early, e0, e1))
+        st["pending"] = keep
+        if st["choice"] is None and all(len(st["times"][k]) >= cls.samples for k in (False, True)):
+            late, early = (sorted(st["times"][k])[len(st["times"][k]) // 2] for k in (False, True))
+            st["choice"] = bool(early < late * (1.0 - cls.margin))
+
+    @classmethod
+    def begin(cls, sig):
+        """-> (early, events or None): the order for this call and, while the workload is still being measured, the pair of
+        events to record around the plan call (pass them to end())."""
+        if cls.mode != "auto":
+            return cls.mode == "early", None
+        st = cls._get(sig)
+        st["calls"] += 1
+        if st["choice"] is not None:
+            return st["choice"], None
+        cls._harvest(st)
+        if st["choice"] is not None:
+            return st["choice"], None
+        if st["calls"] <= cls.warm:
+            return False, None
+        n = {k: len(st["times"][k]) + sum(1 for q in st["pending"] if q[0] == k) for k in (False, True)}
+        if n[False] >= cls.samples and n[True] >= cls.samples:       # everything is in flight: wait for it in the order in use
+            return False, None
+        early = n[True] < n[False]
+        return early, (early, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    @classmethod
+    def end(cls, sig, ev):
+        if ev is not None:
+            cls._get(sig)["pending"].append(ev)
+
+    @classmethod
+    def settled(cls) -> bool:
+        """True when no workload seen so far is still being measured (bench.py: finish this before the timed region)."""
+        if cls.mode != "auto":
+            return True
+        for st in cls._state.values():
+            if st["choice"] is None:
+                cls._harvest(st)
+            if st["choice"] is None:
+                return False
+        return True
+
+    @classmethod
+    def choices(cls):
+        return {str(k): v["choice"] for k, v in cls._state.items()}
+
+
 class ReactionModelFn(torch.autograd.Function):
     """ReactionModel.forward (models/base_model.py:150-171) with an explicit backward."""
 
@@ -1223,8 +1305,15 @@ class ReactionModelFn(torch.autograd.Function):
                 gb = None if b is None else _grad_like(b)
                 G.w[gi], G.b[gi] = ptr(gw), ptr(gb)
                 grads += [gw, gb]
-            check(lib().rr_reaction_backward(C.byref(M), C.byref(S), ptr(dout), C.byref(G), flags, stream()),
-                  "rr_reaction_backward")
+            sig = (st["H"], st["depth"], st["diff_depth"], int(S.mode), int(st["p_graph"].nB) >> 14)
+            early, ev = WgradOrder.begin(sig)
+            if ev is not None:
+                ev[1].record(torch.cuda.current_stream())
+            check(lib().rr_reaction_backward(C.byref(M), C.byref(S), ptr(dout), C.byref(G),
+                                             flags | (_lib.RR_PLAN_WGRAD_EARLY if early else 0), stream()), "rr_reaction_backward")
+            if ev is not None:
+                ev[2].record(torch.cuda.current_stream())
+                WgradOrder.end(sig, ev)
             ctx.plan = "done"
             _WorkspacePool.give(ws)
             return (None, *grads)

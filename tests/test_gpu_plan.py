@@ -110,6 +110,30 @@ def test_plan_last_weight_gradient_on_the_chain_equals_the_side_stream_placement
     _same(a, _run(model, rb, pb, qb, 7, plan=True))
 
 
+@pytest.mark.parametrize("p,dedup,d", [(0.1, "auto", 3), (0.0, False, 3), (0.1, "auto", 5)])
+def test_plan_weight_gradient_in_front_of_its_layers_gemm_equals_the_order_behind_it(p, dedup, d, monkeypatch):
+    """RR_PLAN_WGRAD_EARLY (functions.WgradOrder): same kernels, same order on the weight-gradient stream - every gradient bit
+    for bit in both orders; and the measuring mode settles on one of them without changing a bit either."""
+    cfg = dict(hidden_size=64, mpnn_depth=d, mpnn_diff_depth=d, ffn_depth=3, use_bias=True, task_num=1,
+               ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
+    w = synth.seeded_weights(O.model_shapes(64, d, d, 3, 1, 1, True), 5)
+    model = make_model(cfg, w, dropout=p).train()
+    model.dedup_reactants = dedup
+    qb = synth.make_queries(13, 3, [6, 4, 8], atoms_lo=5, atoms_hi=12)
+    rb, pb = featurization.BatchMolGraph(qb.r_specs, K=4), featurization.BatchMolGraph(qb.p_specs, K=4)
+    monkeypatch.setattr(Fn.WgradOrder, "mode", "late")
+    a = _run(model, rb, pb, qb, 7, plan=True)
+    monkeypatch.setattr(Fn.WgradOrder, "mode", "early")
+    _same(a, _run(model, rb, pb, qb, 7, plan=True))
+    monkeypatch.setattr(Fn.WgradOrder, "mode", "auto")
+    Fn.WgradOrder.reset()
+    for _ in range(Fn.WgradOrder.warm + 2 * Fn.WgradOrder.samples + 2):
+        _same(a, _run(model, rb, pb, qb, 7, plan=True))
+        torch.cuda.synchronize()
+    assert Fn.WgradOrder.settled() and len(Fn.WgradOrder.choices()) == 1
+    Fn.WgradOrder.reset()
+
+
 def test_plan_without_side_and_aux_streams_and_no_grad_forward():
     cfg = dict(hidden_size=64, mpnn_depth=3, mpnn_diff_depth=3, ffn_depth=3, use_bias=True, task_num=1,
                ffn_last_layer="with_softplus", task_type=None, add_features_dim=1)
