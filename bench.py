@@ -187,18 +187,22 @@ class Runner:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def settle(self, batches, limit=40):
+    def settle(self, batches):
+        """Untimed steps, once per Runner, in which the library MEASURES which order of weight gradient and input-gradient GEMM this
+        workload prefers (functions.WgradOrder: ~14 backward calls, the two orders alternated; a step's results are the same bits in
+        either) - a timed region starts in the steady state the rest of a training run sees.  A FIXED number of steps: every
+        step ends in a collective, so all ranks must run the same count whatever their own events say."""
         from reactranker_amd import functions as Fn
-        """Untimed steps until the library has finished MEASURING which order of weight gradient and input-gradient GEMM this
-        workload prefers (functions.WgradOrder: ~14 backward calls per workload, the two orders alternated; the results of a
-        step are the same bits in either) - a timed region starts in the steady state the rest of a training run sees."""
-        n = 0
-        while n < limit and not Fn.WgradOrder.settled():
-            self.train_step(batches(n))
-            n += 1
-            if n % 4 == 0:
+        if getattr(self, "order_tuning_steps", None) is not None or Fn.WgradOrder.mode != "auto":
+            return
+        n = Fn.WgradOrder.warm + 2 * Fn.WgradOrder.samples + 6
+        for i in range(n):
+            self.train_step(batches(i))
+            if i % 4 == 3:
                 self.fence()                              # (let the events of the last calls complete)
-        self.order_tuning_steps = getattr(self, "order_tuning_steps", 0) + n
+        self.fence()
+        Fn.WgradOrder.settled()                           # harvest
+        self.order_tuning_steps = n
 
     def timed(self, batches, n_steps):
         """EXACTLY n_steps optimizer steps between two fences; returns (seconds, per-step device ms list, last loss)."""
@@ -971,7 +975,7 @@ def main():
             "f32_mfma_path": f32_path, other_key: other_path, "epoch_stream": epoch, "presets": presets or None, "dp": dp_info,
             "kernels": ktable, "kernels_isolated": ktable_iso, "final_loss": round(loss_val, 6),
             "host_prep_s": {"synthetic_generation": round(R.t_gen, 2), "native_pack_and_upload": round(R.t_pack, 2)},
-            "wgrad_order": {"mode": Fn.WgradOrder.mode, "untimed_tuning_steps": getattr(R, "order_tuning_steps", 0),
+            "wgrad_order": {"mode": Fn.WgradOrder.mode, "untimed_tuning_steps": getattr(R, "order_tuning_steps", None) or 0,
                             "early_by_workload": Fn.WgradOrder.choices(),
                             "note": "order of a layer's weight gradient and input-gradient GEMM, measured per workload in untimed steps "
                                     "before each timed region (functions.WgradOrder); results are the same bits in either order"},
