@@ -3,7 +3,7 @@ inside the destination's molecule) next to a plain copy of the same tensor.  If 
 extra source, the extra reads (L2 hits: the rows are shared by neighbouring destinations) are what it pays for.
 Usage: python tools/gather_k_scan.py [H]"""
 import os, sys, statistics, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reactranker_amd import functions as Fn
 dev = "cuda"
 torch.manual_seed(0)
